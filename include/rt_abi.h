@@ -1,0 +1,217 @@
+/*
+ * rt_abi.h — C ABI of the MI355X-native per-ray hot path for tatref/raytracer.
+ *
+ * The reference is pure Rust and has no FFI of its own; these entry points are
+ * what a Rust `extern "C"` block (bindgen output of this header) binds so that
+ * the 2d crate's `ReverseRenderer::{global_render, render_column, compute_pixel,
+ * trace_ray}` (2d/src/librt2d_reverse.rs:80-302) and the 3d crate's
+ * `World::{render, compute_pixel, trace_ray}` (3d/src/rt.rs:216-273) keep their
+ * Rust signatures and run on the GPU.  Every declaration cites the reference
+ * code it replaces (paths relative to the reference root).
+ *
+ * Conventions
+ *  - plain pointers and sizes only; every function returns 0 on success or a
+ *    negative RT_E_* code; no exception or abort crosses the boundary;
+ *    `rt_last_error()` returns the calling thread's last message.
+ *  - inputs are borrowed for the duration of the call and copied where they
+ *    must outlive it (scene creation); outputs are caller-allocated; handles
+ *    are freed only by the matching *_destroy.
+ *  - a context is bound to one GPU; it may be used from any host thread but
+ *    not from two threads at once (the reference calls global_render from a
+ *    worker thread, 2d/src/bin/gui.rs:171-187, one render at a time).
+ *  - arithmetic: f64 geometry, f32 radiance, no fused multiply-add — the
+ *    reference's arithmetic (2d/src/rt_common.rs:61-64, spectrum.rs:113-115).
+ *  - randomness: counter-based Philox4x32-10 keyed by `seed`; the reference's
+ *    thread-local unseeded generator (librt2d_reverse.rs:89, rt_common.rs:370,
+ *    379-380, spectrum.rs:186, 3d/src/rt.rs:41,181) has no reproducible
+ *    stream to match.
+ *  - there is no CPU fallback: every compute entry point fails with
+ *    RT_E_NO_DEVICE when no gfx950 device is usable.
+ */
+#ifndef RT_ABI_H
+#define RT_ABI_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT_NBINS 95 /* SPECTRUM_SAMPLES, 2d/src/spectrum.rs:106 */
+
+enum {
+    RT_OK = 0,
+    RT_E_INVALID = -1,   /* bad argument / malformed scene */
+    RT_E_NO_DEVICE = -2, /* no usable GPU; there is no CPU path */
+    RT_E_HIP = -3,       /* a HIP runtime call failed */
+    RT_E_OOM = -4,
+    RT_E_LIMIT = -5      /* size beyond what the kernels support */
+};
+
+/* Material variants, 2d/src/rt_common.rs:403-431 */
+enum {
+    RT_MAT_EMISSIVE = 0,
+    RT_MAT_DIRECTIONAL_EMISSIVE = 1,
+    RT_MAT_DIFFUSE = 2,
+    RT_MAT_REFLECTIVE = 3,
+    RT_MAT_DIELECTRIC = 4
+};
+
+/* One entry per reference `Object` (rt_common.rs:486-490): its Material with the
+ * Spectrum moved into the shared spectra table.  Ior: rt_common.rs:433-450.   */
+typedef struct rt2d_material {
+    int32_t kind;
+    int32_t ior_kind; /* 0 = Ior::Simple(ior_a), 1 = Ior::Cauchy{a: ior_a, b: ior_b} */
+    double ior_a, ior_b;
+    double angle, d;  /* DirectionalEmissive */
+    int32_t spectrum; /* row of `spectra`: emission / Diffuse albedo / Dielectric absorption */
+    int32_t pad_;
+} rt2d_material;
+
+/* Flat SoA form of `World.objects` (rt_common.rs:541-546): circles
+ * (rt_common.rs:60-64) and segments (rt_common.rs:201-206, every Strip expanded).
+ * `*_obj` = index of the owning object; `*_pid` = position of the primitive in
+ * the reference's scan order (object order, then segment order inside a strip):
+ * nearest-hit ties go to the lowest pid, as `min_by` / `Strip::hit` do
+ * (librt2d_reverse.rs:135-139, rt_common.rs:295-305).  pids are 0..P-1, unique. */
+typedef struct rt2d_scene_desc {
+    int32_t n_circles, n_segments, n_objects, n_spectra;
+    const double *circle_cx, *circle_cy, *circle_r;
+    const int32_t *circle_obj, *circle_pid;
+    const double *seg_ax, *seg_ay, *seg_bx, *seg_by, *seg_nx, *seg_ny;
+    const int32_t *seg_obj, *seg_pid;
+    const rt2d_material *materials; /* [n_objects] */
+    const float *spectra;           /* [n_spectra][RT_NBINS] */
+} rt2d_scene_desc;
+
+/* ReverseRenderParams, librt2d_reverse.rs:43-52, plus what the reference leaves
+ * implicit: the RNG seed, the global index of the first sample (sample-batch
+ * sharding / progressive passes) and the pixel->world scale (the reference
+ * renders 800x600 with pixel == world, librt2d_reverse.rs:89; 1.0 reproduces it,
+ * 800.0/width keeps its scenes framed at other resolutions).                  */
+typedef struct rt2d_render_params {
+    int32_t width, height;
+    int32_t spp;
+    int32_t lambda_samples;
+    int32_t recursion_limit;
+    int32_t sample_offset;
+    uint64_t seed;
+    double px_to_world;
+} rt2d_render_params;
+
+/* 3d: `World.objects` (all Object::Sphere, 3d/src/rt.rs:47-69) and the arguments
+ * of Camera::new (3d/src/rt.rs:139-147).                                      */
+typedef struct rt3d_scene_desc {
+    int32_t n_spheres;
+    int32_t use_bvh; /* 0 = linear scan as the reference (rt.rs:221-224), 1 = BVH over sphere AABBs */
+    const double *cx, *cy, *cz, *r;
+    double cam_pos[3], cam_dir[3], cam_up[3];
+    double focal_length;
+    int32_t width, height;
+} rt3d_scene_desc;
+
+/* RenderParams, 3d/src/rt.rs:194-197 */
+typedef struct rt3d_render_params {
+    int32_t spp, bounce_limit, sample_offset, pad_;
+    uint64_t seed;
+} rt3d_render_params;
+
+/* Counters since context creation or the last rt_ctx_reset_stats. */
+typedef struct rt_stats {
+    uint64_t rays;      /* trace_ray invocations with depth > 0 (nearest-hit queries) */
+    uint64_t samples;   /* top-level trace_ray calls */
+    uint64_t launches;  /* trace-kernel launches */
+    double kernel_ms;   /* summed duration of those launches, HIP events on the context's stream */
+} rt_stats;
+
+typedef struct rt_ctx rt_ctx;
+typedef struct rt2d_scene rt2d_scene;
+typedef struct rt3d_scene rt3d_scene;
+
+/* ---- library / context --------------------------------------------------- */
+const char *rt_version(void);
+const char *rt_last_error(void);
+int32_t rt_device_count(int32_t *count);
+int32_t rt_ctx_create(int32_t device_id, rt_ctx **out);
+int32_t rt_ctx_destroy(rt_ctx *ctx);
+/* Work is enqueued on `hip_stream` (a hipStream_t; NULL = the context's own stream). */
+int32_t rt_ctx_set_stream(rt_ctx *ctx, void *hip_stream);
+int32_t rt_ctx_synchronize(rt_ctx *ctx);
+/* Both synchronize the stream first. */
+int32_t rt_ctx_get_stats(rt_ctx *ctx, rt_stats *out);
+int32_t rt_ctx_reset_stats(rt_ctx *ctx);
+
+/* ---- 2d: scene ----------------------------------------------------------- */
+/* Replaces borrowing `&World` (librt2d_reverse.rs:82,114): the arrays are copied. */
+int32_t rt2d_scene_create(rt_ctx *ctx, const rt2d_scene_desc *desc, rt2d_scene **out);
+int32_t rt2d_scene_destroy(rt2d_scene *scene);
+
+/* ---- 2d: whole image ------------------------------------------------------
+ * ReverseRenderer::global_render (librt2d_reverse.rs:282-302) for one pass of
+ * `spp` samples: out_rgb[W*y+x][3] = Spectrum::to_dvec3 of the pixel's mean
+ * spectrum (spectrum.rs:242-278), out_weight[W*y+x] = spp (librt2d_reverse.rs:
+ * 291-294, img.rs:20-24,93-99); out_spectrum (nullable) [W*y+x][95] = the value
+ * compute_pixel returns.  Host pointers.                                      */
+int32_t rt2d_render(rt_ctx *ctx, const rt2d_scene *scene, const rt2d_render_params *params,
+                    float *out_rgb, float *out_weight, float *out_spectrum);
+
+/* The two halves of rt2d_render on device memory, for sample-batch sharding over
+ * GPUs and progressive passes (the role of `merged_image + loop_image`,
+ * librt2d_reverse.rs:463-467, done on linear spectra):
+ * rt2d_accumulate ADDS this call's samples into d_spectrum (device f32
+ * [W*H][95]; per-sample term = value / lambda_samples * 95, librt2d_reverse.rs:
+ * 102-107); rt2d_resolve divides by total_spp (:109), converts to sRGB
+ * (spectrum.rs:242-278) and writes host out_rgb / out_weight (either nullable)
+ * and, if d_rgb is non-NULL, device f32 [W*H][3].                             */
+int32_t rt2d_accumulate(rt_ctx *ctx, const rt2d_scene *scene, const rt2d_render_params *params,
+                        void *d_spectrum);
+int32_t rt2d_resolve(rt_ctx *ctx, const void *d_spectrum, int32_t width, int32_t height,
+                     int32_t total_spp, void *d_rgb, float *out_rgb, float *out_weight);
+
+/* ---- 2d: pixel lists ------------------------------------------------------
+ * ReverseRenderer::compute_pixel (librt2d_reverse.rs:80-110) for n pixels at
+ * once; out_spectrum[k][95] is the returned Spectrum of pixel (px[k], py[k]).
+ * render_column (librt2d_reverse.rs:264-279) is the list {(i, j) : j in 0..H};
+ * the denoiser's re-sampling pass (librt2d_reverse.rs:407-413) is an arbitrary
+ * list.  Pixels outside the image are legal (the reference computes them too). */
+int32_t rt2d_compute_pixels(rt_ctx *ctx, const rt2d_scene *scene, const rt2d_render_params *params,
+                            int64_t n, const int32_t *px, const int32_t *py, float *out_spectrum);
+
+/* ---- 2d: fed ray batches --------------------------------------------------
+ * ReverseRenderer::trace_ray (librt2d_reverse.rs:112-262) for n rays:
+ * radiance[k] = trace_ray(world, Ray2d{(ox,oy),(dx,dy)}, lambda_idx[k],
+ * 5*lambda_idx[k]+360, depth).  Also returns what the reference computes but
+ * does not return: pid of the first nearest hit (-1 = miss), its distance
+ * (-1.0 = miss) and the number of trace_ray invocations with depth > 0.
+ * Optional outputs may be NULL.  Host pointers.                               */
+int32_t rt2d_trace_batch(rt_ctx *ctx, const rt2d_scene *scene, int64_t n, const double *ox,
+                         const double *oy, const double *dx, const double *dy,
+                         const int32_t *lambda_idx, int32_t depth, uint64_t seed, float *radiance,
+                         int32_t *first_prim, double *first_t, int32_t *bounces);
+
+/* ---- 3d ------------------------------------------------------------------- */
+int32_t rt3d_scene_create(rt_ctx *ctx, const rt3d_scene_desc *desc, rt3d_scene **out);
+int32_t rt3d_scene_destroy(rt3d_scene *scene);
+/* World::render (3d/src/rt.rs:252-273): out_rgb[W*(H-1-j)+i][3] = sum over spp of
+ * trace_ray (no mean, rt.rs:239-246); the 10x10 corner i<10 && j<10 stays 0.  */
+int32_t rt3d_render(rt_ctx *ctx, const rt3d_scene *scene, const rt3d_render_params *params,
+                    float *out_rgb);
+/* Device-memory form: ADDS this call's samples into d_rgb (device f32 [W*H][3]). */
+int32_t rt3d_accumulate(rt_ctx *ctx, const rt3d_scene *scene, const rt3d_render_params *params,
+                        void *d_rgb);
+/* World::trace_ray (3d/src/rt.rs:216-236) for n rays; o, d are [n][3]. */
+int32_t rt3d_trace_batch(rt_ctx *ctx, const rt3d_scene *scene, int64_t n, const double *o,
+                         const double *d, int32_t bounce_limit, uint64_t seed, float *rgb,
+                         int32_t *first_prim, double *first_t, int32_t *bounces);
+
+/* ---- image output ---------------------------------------------------------
+ * RawImage::convert_to_image(Reinhard{param}) (2d/src/img.rs:187-218, alpha 255;
+ * 3d/src/img.rs:126-157, param 1, alpha 254): rgba8 = (v / (param + v) * 255) as u8.
+ * Host pointers; runs on the GPU like everything else here.                   */
+int32_t rt_tonemap_reinhard(rt_ctx *ctx, const float *rgb, int64_t n_pixels, float param,
+                            uint8_t alpha, uint8_t *out_rgba8);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_ABI_H */

@@ -1,0 +1,281 @@
+"""Object wrappers over the C ABI (see _ffi.py).  Names follow the reference:
+World, ReverseRenderParams fields, global_render / compute_pixel / trace_ray."""
+import ctypes as C
+
+import numpy as np
+
+from . import _ffi
+from ._ffi import NBINS, RenderParams2D, RenderParams3D, RtError, Scene2DDesc, Scene3DDesc, Stats, check  # noqa: F401
+
+
+class World2D:
+    """A scene of 2d/src/worlds.rs built by the C++ host mirror, flattened to the SoA
+    arrays of rt2d_scene_desc.  `desc` stays valid while this object lives."""
+
+    NAMES = ("sample_world", "complex_world", "cornell_box", "cornell_box_absorption", "cornell_box_sss",
+             "spectrum_world", "simple_world")
+
+    def __init__(self, name, t=0.0, idx=0, seed=1, width=800.0, height=600.0):
+        h = _ffi.host()
+        self._h = h.rth_world2d_build(name.encode(), float(t), int(idx), int(seed), float(width), float(height))
+        if not self._h:
+            raise ValueError(h.rth_last_error().decode())
+        self.desc = Scene2DDesc()
+        if h.rth_world2d_desc(self._h, C.byref(self.desc)) != 0:
+            raise ValueError(h.rth_last_error().decode())
+        self.name = name
+
+    @property
+    def n_prims(self):
+        return self.desc.n_circles + self.desc.n_segments
+
+    def arrays(self):
+        """numpy copies of the SoA arrays (for fixtures and inspection)."""
+        d = self.desc
+        nc, ns = d.n_circles, d.n_segments
+
+        def arr(p, n, dt):
+            return np.ctypeslib.as_array(p, shape=(n,)).astype(dt).copy() if n else np.zeros(0, dt)
+
+        out = {k: arr(getattr(d, k), nc, np.float64) for k in ("circle_cx", "circle_cy", "circle_r")}
+        out.update({k: arr(getattr(d, k), nc, np.int32) for k in ("circle_obj", "circle_pid")})
+        out.update({k: arr(getattr(d, k), ns, np.float64) for k in ("seg_ax", "seg_ay", "seg_bx", "seg_by", "seg_nx", "seg_ny")})
+        out.update({k: arr(getattr(d, k), ns, np.int32) for k in ("seg_obj", "seg_pid")})
+        mats = np.zeros((d.n_objects, 7), np.float64)
+        for i in range(d.n_objects):
+            m = d.materials[i]
+            mats[i] = (m.kind, m.ior_kind, m.ior_a, m.ior_b, m.angle, m.d, m.spectrum)
+        out["materials"] = mats
+        out["spectra"] = arr(d.spectra, d.n_spectra * NBINS, np.float32).reshape(d.n_spectra, NBINS)
+        return out
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _ffi.host().rth_world2d_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+
+class ArrayWorld2D:
+    """rt2d_scene_desc over caller-owned numpy arrays (keys as World2D.arrays())."""
+
+    def __init__(self, arrays):
+        a = self._a = {k: np.ascontiguousarray(v) for k, v in arrays.items()}
+        d = self.desc = Scene2DDesc()
+        d.n_circles, d.n_segments = len(a["circle_cx"]), len(a["seg_ax"])
+        d.n_objects, d.n_spectra = len(a["materials"]), len(a["spectra"])
+        for k in ("circle_cx", "circle_cy", "circle_r", "seg_ax", "seg_ay", "seg_bx", "seg_by", "seg_nx", "seg_ny"):
+            a[k] = np.ascontiguousarray(a[k], np.float64)
+            setattr(d, k, _ffi.ptr(a[k], C.c_double))
+        for k in ("circle_obj", "circle_pid", "seg_obj", "seg_pid"):
+            a[k] = np.ascontiguousarray(a[k], np.int32)
+            setattr(d, k, _ffi.ptr(a[k], C.c_int32))
+        self._mats = (_ffi.Material2D * max(1, d.n_objects))()
+        for i, row in enumerate(np.asarray(a["materials"], np.float64)):
+            m = self._mats[i]
+            m.kind, m.ior_kind, m.ior_a, m.ior_b, m.angle, m.d, m.spectrum = (
+                int(row[0]), int(row[1]), row[2], row[3], row[4], row[5], int(row[6]))
+        d.materials = C.cast(self._mats, C.POINTER(_ffi.Material2D))
+        a["spectra"] = np.ascontiguousarray(a["spectra"], np.float32)
+        d.spectra = _ffi.ptr(a["spectra"], C.c_float)
+
+    @property
+    def n_prims(self):
+        return self.desc.n_circles + self.desc.n_segments
+
+
+class Standalone3D:
+    """Scene + camera of 3d/src/bin/standalone.rs at a given image size."""
+
+    def __init__(self, width=640, height=480, use_bvh=True):
+        h = _ffi.host()
+        self.desc = Scene3DDesc()
+        self._h = h.rth_scene3d_standalone(int(width), int(height), 1 if use_bvh else 0, C.byref(self.desc))
+        if not self._h:
+            raise ValueError(h.rth_last_error().decode())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _ffi.host().rth_scene3d_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+
+class Context:
+    """One GPU.  Work is enqueued on `stream` (a hipStream_t handle, e.g.
+    torch.cuda.current_stream().cuda_stream) or on the context's own stream."""
+
+    def __init__(self, device=0, stream=None):
+        self._ctx = C.c_void_p()
+        check(_ffi.lib().rt_ctx_create(int(device), C.byref(self._ctx)))
+        if stream is not None:
+            self.set_stream(stream)
+
+    def set_stream(self, stream):
+        check(_ffi.lib().rt_ctx_set_stream(self._ctx, C.c_void_p(stream) if stream else None))
+
+    def synchronize(self):
+        check(_ffi.lib().rt_ctx_synchronize(self._ctx))
+
+    def stats(self):
+        s = Stats()
+        check(_ffi.lib().rt_ctx_get_stats(self._ctx, C.byref(s)))
+        return {"rays": s.rays, "samples": s.samples, "launches": s.launches, "kernel_ms": s.kernel_ms}
+
+    def reset_stats(self):
+        check(_ffi.lib().rt_ctx_reset_stats(self._ctx))
+
+    def tonemap_reinhard(self, rgb, param=1.0, alpha=255):
+        rgb = np.ascontiguousarray(rgb, np.float32).reshape(-1, 3)
+        out = np.empty((rgb.shape[0], 4), np.uint8)
+        check(_ffi.lib().rt_tonemap_reinhard(self._ctx, _ffi.ptr(rgb, C.c_float), rgb.shape[0], float(param), int(alpha),
+                                             _ffi.ptr(out, C.c_uint8)))
+        return out
+
+    def close(self):
+        if getattr(self, "_ctx", None):
+            _ffi.lib().rt_ctx_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def params2d(width, height, spp, lambda_samples, recursion_limit, seed=0, sample_offset=0, px_to_world=None):
+    p = RenderParams2D()
+    p.width, p.height, p.spp, p.lambda_samples = int(width), int(height), int(spp), int(lambda_samples)
+    p.recursion_limit, p.sample_offset, p.seed = int(recursion_limit), int(sample_offset), int(seed)
+    p.px_to_world = float(800.0 / width if px_to_world is None else px_to_world)
+    return p
+
+
+class Scene2D:
+    """A World uploaded to one GPU; methods named after ReverseRenderer's."""
+
+    def __init__(self, ctx, world):
+        self.ctx = ctx
+        self._world = world  # keeps the desc arrays alive during creation
+        self._sc = C.c_void_p()
+        check(_ffi.lib().rt2d_scene_create(ctx._ctx, C.byref(world.desc), C.byref(self._sc)))
+        self.n_prims = world.n_prims
+
+    def global_render(self, p, want_spectrum=False):
+        n = p.width * p.height
+        rgb = np.empty((p.height, p.width, 3), np.float32)
+        weight = np.empty((p.height, p.width), np.float32)
+        spec = np.empty((p.height, p.width, NBINS), np.float32) if want_spectrum else None
+        check(_ffi.lib().rt2d_render(self.ctx._ctx, self._sc, C.byref(p), _ffi.ptr(rgb, C.c_float),
+                                     _ffi.ptr(weight, C.c_float), _ffi.ptr(spec, C.c_float)))
+        assert rgb.size == 3 * n
+        return (rgb, weight, spec) if want_spectrum else (rgb, weight)
+
+    def accumulate(self, p, d_spectrum_ptr):
+        check(_ffi.lib().rt2d_accumulate(self.ctx._ctx, self._sc, C.byref(p), C.c_void_p(d_spectrum_ptr)))
+
+    def resolve(self, d_spectrum_ptr, width, height, total_spp, d_rgb_ptr=None, to_host=True):
+        rgb = np.empty((height, width, 3), np.float32) if to_host else None
+        weight = np.empty((height, width), np.float32) if to_host else None
+        check(_ffi.lib().rt2d_resolve(self.ctx._ctx, C.c_void_p(d_spectrum_ptr), int(width), int(height), int(total_spp),
+                                      C.c_void_p(d_rgb_ptr) if d_rgb_ptr else None, _ffi.ptr(rgb, C.c_float),
+                                      _ffi.ptr(weight, C.c_float)))
+        return rgb, weight
+
+    def compute_pixels(self, p, px, py):
+        px, py = _ffi.as_i32(px), _ffi.as_i32(py)
+        out = np.empty((len(px), NBINS), np.float32)
+        check(_ffi.lib().rt2d_compute_pixels(self.ctx._ctx, self._sc, C.byref(p), len(px), _ffi.ptr(px, C.c_int32),
+                                             _ffi.ptr(py, C.c_int32), _ffi.ptr(out, C.c_float)))
+        return out
+
+    def render_column(self, p, i):
+        return self.compute_pixels(p, np.full(p.height, i, np.int32), np.arange(p.height, dtype=np.int32))
+
+    def compute_pixel(self, p, x, y):
+        return self.compute_pixels(p, [x], [y])[0]
+
+    def trace_batch(self, ox, oy, dx, dy, lambda_idx, depth, seed=0):
+        ox, oy, dx, dy = (_ffi.as_f64(a) for a in (ox, oy, dx, dy))
+        li = _ffi.as_i32(lambda_idx)
+        n = len(ox)
+        rad = np.empty(n, np.float32)
+        fp = np.empty(n, np.int32)
+        ft = np.empty(n, np.float64)
+        nb = np.empty(n, np.int32)
+        check(_ffi.lib().rt2d_trace_batch(self.ctx._ctx, self._sc, n, _ffi.ptr(ox, C.c_double), _ffi.ptr(oy, C.c_double),
+                                          _ffi.ptr(dx, C.c_double), _ffi.ptr(dy, C.c_double), _ffi.ptr(li, C.c_int32),
+                                          int(depth), int(seed), _ffi.ptr(rad, C.c_float), _ffi.ptr(fp, C.c_int32),
+                                          _ffi.ptr(ft, C.c_double), _ffi.ptr(nb, C.c_int32)))
+        return rad, fp, ft, nb
+
+    def close(self):
+        if getattr(self, "_sc", None):
+            _ffi.lib().rt2d_scene_destroy(self._sc)
+            self._sc = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def params3d(spp, bounce_limit, seed=0, sample_offset=0):
+    p = RenderParams3D()
+    p.spp, p.bounce_limit, p.sample_offset, p.seed = int(spp), int(bounce_limit), int(sample_offset), int(seed)
+    return p
+
+
+class Scene3D:
+    """Spheres + camera uploaded to one GPU; methods named after the 3d crate's World."""
+
+    def __init__(self, ctx, scene):
+        self.ctx = ctx
+        self._scene = scene
+        self.width, self.height = scene.desc.width, scene.desc.height
+        self._sc = C.c_void_p()
+        check(_ffi.lib().rt3d_scene_create(ctx._ctx, C.byref(scene.desc), C.byref(self._sc)))
+
+    def render(self, p):
+        out = np.empty((self.height, self.width, 3), np.float32)
+        check(_ffi.lib().rt3d_render(self.ctx._ctx, self._sc, C.byref(p), _ffi.ptr(out, C.c_float)))
+        return out
+
+    def accumulate(self, p, d_rgb_ptr):
+        check(_ffi.lib().rt3d_accumulate(self.ctx._ctx, self._sc, C.byref(p), C.c_void_p(d_rgb_ptr)))
+
+    def trace_batch(self, o, d, bounce_limit, seed=0):
+        o, d = _ffi.as_f64(o).reshape(-1, 3), _ffi.as_f64(d).reshape(-1, 3)
+        n = o.shape[0]
+        rgb = np.empty((n, 3), np.float32)
+        fp = np.empty(n, np.int32)
+        ft = np.empty(n, np.float64)
+        nb = np.empty(n, np.int32)
+        check(_ffi.lib().rt3d_trace_batch(self.ctx._ctx, self._sc, n, _ffi.ptr(o, C.c_double), _ffi.ptr(d, C.c_double),
+                                          int(bounce_limit), int(seed), _ffi.ptr(rgb, C.c_float), _ffi.ptr(fp, C.c_int32),
+                                          _ffi.ptr(ft, C.c_double), _ffi.ptr(nb, C.c_int32)))
+        return rgb, fp, ft, nb
+
+    def close(self):
+        if getattr(self, "_sc", None):
+            _ffi.lib().rt3d_scene_destroy(self._sc)
+            self._sc = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def write_png(path, rgba8, width, height):
+    rgba8 = np.ascontiguousarray(rgba8, np.uint8)
+    rc = _ffi.host().rth_png_write(str(path).encode(), _ffi.ptr(rgba8, C.c_uint8), int(width), int(height))
+    if rc != 0:
+        raise OSError(_ffi.host().rth_last_error().decode())

@@ -1,0 +1,360 @@
+// 2d spectral gather tracer: device-side nearest-hit search, shading and ray
+// generation.  One lane owns one path; primitives are wave-uniform operands.
+//
+// Reference semantics (paths relative to the reference root):
+//   nearest hit    2d/src/librt2d_reverse.rs:135-139, rt_common.rs:79-111 (Circle::hit),
+//                  :242-276 (Segment::hit), :295-305 (Strip::hit)
+//   shading        2d/src/librt2d_reverse.rs:146-261
+//   ray generation 2d/src/librt2d_reverse.rs:88-94, rt_common.rs:369-391, spectrum.rs:185-191
+#pragma once
+
+#include "rt_device_math.hpp"
+
+namespace rt2d {
+using namespace rtd;
+
+enum { MAT_EMISSIVE = 0, MAT_DIRECTIONAL = 1, MAT_DIFFUSE = 2, MAT_REFLECTIVE = 3, MAT_DIELECTRIC = 4 };
+
+struct MatDev {
+    int32_t kind, ior_kind;
+    double ior_a, ior_b, angle, d;
+    int32_t spectrum;
+    int32_t black; // Diffuse whose spectrum is all zero (`absorption == Spectrum::default()`, librt2d_reverse.rs:212)
+};
+
+// Scene in HBM, struct-of-arrays.  Slot order: circles by ascending pid, then
+// segments by ascending pid.  cr2 = r*r and (ssx, ssy) = b - a are the values the
+// reference recomputes in every hit test (rt_common.rs:83, :244).
+struct SceneDev {
+    int32_t n_circ, n_seg, n_obj, pad_;
+    const double *ccx, *ccy, *cr2;
+    const double *sax, *say, *ssx, *ssy, *snx, *sny;
+    const int32_t *cobj, *cpid, *sobj, *spid;
+    const MatDev *mats;
+    const float *spectra;
+};
+
+struct Hit {
+    double t;
+    int32_t slot; // < 0: miss
+    int32_t pid;
+};
+
+// ---------------------------------------------------------------------------
+// Exact (reference-order) single primitive tests, used on the few candidates
+// that survive the sign filters below.
+RT_DEV bool circle_t(double ox, double oy, double dx, double dy, double cx, double cy, double r2, double &t)
+{
+    const double ocx = ox - cx, ocy = oy - cy;
+    const double a = 1.0;
+    const double b = 2.0 * (dx * ocx + dy * ocy);
+    const double c = (ocx * ocx + ocy * ocy) - r2;
+    const double delta = b * b - 4.0 * a * c;
+    if (delta < 0.0) return false;
+    const double sq = __builtin_sqrt(delta);
+    const double t0 = (-b - sq) / (2.0 * a);
+    const double t1 = (-b + sq) / (2.0 * a);
+    if (t0 > 0.0) { t = t0; return true; }
+    if (t1 > 0.0) { t = t1; return true; }
+    return false;
+}
+
+RT_DEV bool segment_t(double ox, double oy, double rx, double ry, double ax, double ay, double sx, double sy, double &t)
+{
+    const double denom = rx * sy - ry * sx;
+    if (__builtin_fabs(denom) < EPS64) return false;
+    const double qx = ax - ox, qy = ay - oy;
+    const double tt = (qx * sy - qy * sx) / denom;
+    const double u = (qx * ry - qy * rx) / denom;
+    if (tt >= 0.0 && u >= 0.0 && u <= 1.0) { t = tt; return true; }
+    return false;
+}
+
+// ---------------------------------------------------------------------------
+// Nearest hit over the whole scene, brute force, in two phases per tile of 256
+// slots:
+//  phase 1 (uniform loop, every lane x every primitive): the reference's own
+//    f64 products and sums up to the discriminant (circle) or the three cross
+//    products (segment), then SIGN-BIT logic only — no sqrt, no division, no
+//    compare — marks the lanes for which the primitive can still be a hit.
+//    The filter never drops a true hit:
+//      circle : the reference rejects delta < 0, and with b >= 0 and c >= 0 both
+//               roots are <= 0 (sqrt(delta) <= sqrt(fl(b*b)) = b); the filter
+//               keeps delta' >= 0 && (b' < 0 || c < 0) where b' = b/2 and
+//               delta' = delta/4 are exact power-of-two rescalings (radii are
+//               validated >= 2^-400 so no term of delta underflows unequally).
+//      segment: t = tn/den >= 0 and 0 <= u = un/den <= 1 fail for sure when tn
+//               (or un) is not tiny (|.| >= 2^-900) and differs in sign from den,
+//               or when |un| exceeds |den| by more than 2^-20 relative; scene
+//               and ray magnitudes are validated so |den| <= 2^62 and such a
+//               quotient cannot round to -0.0.
+//  phase 2 (per-lane loop over its marked slots, ascending): the exact test in
+//    the reference's operation order, then (total_cmp key, pid) lexicographic
+//    minimum = "first minimum in scan order" (librt2d_reverse.rs:139).
+// Inactive lanes run phase 1 with the wave and skip phase 2.
+RT_DEV uint32_t filter_word(const SceneDev &S, int lo, int hi, double ox, double oy, double dx, double dy)
+{
+    uint32_t acc = 0;
+    const int c_end = hi < S.n_circ ? hi : S.n_circ;
+#pragma unroll 2
+    for (int s = lo; s < c_end; ++s) {
+        const double cx = S.ccx[s], cy = S.ccy[s], r2 = S.cr2[s];
+        const double ocx = ox - cx, ocy = oy - cy;
+        const double bp = dx * ocx + dy * ocy;
+        const double cc = (ocx * ocx + ocy * ocy) - r2;
+        const double dl = bp * bp - cc;
+        // keep iff !sign(dl) && (sign(bp) || sign(cc))
+        const uint32_t keep = (uint32_t)(~hi32(dl) & (hi32(bp) | hi32(cc)));
+        acc = __builtin_amdgcn_alignbit(acc, keep, 31);
+    }
+    const int s_lo = lo > S.n_circ ? lo : S.n_circ;
+#pragma unroll 2
+    for (int s = s_lo; s < hi; ++s) {
+        const int k = s - S.n_circ;
+        const double ax = S.sax[k], ay = S.say[k], sx = S.ssx[k], sy = S.ssy[k];
+        const double den = dx * sy - dy * sx;
+        const double qx = ax - ox, qy = ay - oy;
+        const double tn = qx * sy - qy * sx;
+        const double un = qx * dy - qy * dx;
+        const uint32_t dh = (uint32_t)hi32(den), th = (uint32_t)hi32(tn), uh = (uint32_t)hi32(un);
+        const uint32_t TINY = (1023u - 900u) << 20;
+        // sign-magnitude copies of tn, un with the sign taken relative to den
+        const uint32_t st = ((th ^ dh) & 0x80000000u) | (th & 0x7fffffffu);
+        const uint32_t su = ((uh ^ dh) & 0x80000000u) | (uh & 0x7fffffffu);
+        const uint32_t rej_t = (st - TINY) & st;           // negative and not tiny
+        const uint32_t rej_u0 = (su - TINY) & su;
+        const uint32_t rej_u1 = ((dh & 0x7fffffffu) + 1u) - (uh & 0x7fffffffu); // |un|_hi > |den|_hi + 1
+        const uint32_t rej = rej_t | rej_u0 | rej_u1;
+        acc = __builtin_amdgcn_alignbit(acc, ~rej, 31);
+    }
+    return acc << (32 - (hi - lo));
+}
+
+RT_DEV Hit nearest_hit(const SceneDev &S, double ox, double oy, double dx, double dy, bool active)
+{
+    Hit best;
+    best.t = 0.0;
+    best.slot = -1;
+    best.pid = 0x7fffffff;
+    int64_t best_key = 0x7fffffffffffffffLL;
+    const int P = S.n_circ + S.n_seg;
+    for (int base = 0; base < P; base += 256) {
+        uint32_t m[8];
+#pragma unroll
+        for (int w = 0; w < 8; ++w) {
+            const int lo = base + 32 * w;
+            const int hi = (lo + 32 < P) ? lo + 32 : P;
+            m[w] = (lo < P) ? filter_word(S, lo, hi, ox, oy, dx, dy) : 0u;
+        }
+        uint64_t m0 = ((uint64_t)m[0] << 32) | m[1], m1 = ((uint64_t)m[2] << 32) | m[3];
+        uint64_t m2 = ((uint64_t)m[4] << 32) | m[5], m3 = ((uint64_t)m[6] << 32) | m[7];
+        if (!active) { m0 = m1 = m2 = m3 = 0; }
+        while ((m0 | m1 | m2 | m3) != 0) {
+            const int w = m0 ? 0 : m1 ? 1 : m2 ? 2 : 3;
+            const uint64_t cur = m0 ? m0 : m1 ? m1 : m2 ? m2 : m3;
+            const int b = __clzll((long long)cur);
+            const uint64_t rest = cur & ~(0x8000000000000000ULL >> b);
+            m0 = (w == 0) ? rest : m0;
+            m1 = (w == 1) ? rest : m1;
+            m2 = (w == 2) ? rest : m2;
+            m3 = (w == 3) ? rest : m3;
+            const int s = base + 64 * w + b;
+            double t;
+            bool got;
+            int pid;
+            if (s < S.n_circ) {
+                got = circle_t(ox, oy, dx, dy, S.ccx[s], S.ccy[s], S.cr2[s], t);
+                pid = S.cpid[s];
+            } else {
+                const int k = s - S.n_circ;
+                got = segment_t(ox, oy, dx, dy, S.sax[k], S.say[k], S.ssx[k], S.ssy[k], t);
+                pid = S.spid[k];
+            }
+            if (got) {
+                const int64_t key = total_key(t);
+                if (key < best_key || (key == best_key && pid < best.pid)) {
+                    best_key = key;
+                    best.t = t;
+                    best.slot = s;
+                    best.pid = pid;
+                }
+            }
+        }
+    }
+    return best;
+}
+
+// ---------------------------------------------------------------------------
+// Path state of one lane.
+struct Path {
+    double ox, oy, dx, dy;
+    float thr;          // product of the factors collected so far (albedo, Beer-Lambert)
+    int32_t li;         // wavelength bin
+    int32_t depth_left; // the reference's `depth` argument
+    uint32_t c0, c1, c2; // Philox counter words naming this path
+};
+
+enum ShadeResult { SHADE_CONTINUE = 0, SHADE_DONE = 1 };
+
+// One trace_ray body after the nearest hit is known (librt2d_reverse.rs:146-261).
+// Returns SHADE_DONE with `value` = the radiance this invocation returns to its
+// caller (to be multiplied by the path's collected factors), or SHADE_CONTINUE
+// with the path advanced to the recursive call's ray.
+RT_DEV ShadeResult shade(const SceneDev &S, Path &p, const Hit &h, int recursion_limit, uint32_t k0, uint32_t k1,
+                         float &value)
+{
+    value = 0.0f;
+    if (h.slot < 0) return SHADE_DONE;
+    double hx, hy, nx, ny;
+    bool outside;
+    int obj;
+    if (h.slot < S.n_circ) {
+        const int s = h.slot;
+        const double cx = S.ccx[s], cy = S.ccy[s];
+        hx = p.ox + h.t * p.dx;
+        hy = p.oy + h.t * p.dy;
+        const double vx = hx - cx, vy = hy - cy;
+        const double rl = rlen2(vx, vy);
+        nx = vx * rl;
+        ny = vy * rl;
+        const double ex = cx - p.ox, ey = cy - p.oy;
+        outside = !((ex * ex + ey * ey) < S.cr2[s]);
+        obj = S.cobj[s];
+    } else {
+        const int k = h.slot - S.n_circ;
+        hx = p.ox + h.t * p.dx;
+        hy = p.oy + h.t * p.dy;
+        nx = S.snx[k];
+        ny = S.sny[k];
+        outside = (nx * p.dx + ny * p.dy) < 0.0;
+        obj = S.sobj[k];
+    }
+    const MatDev m = S.mats[obj];
+    const float sv = S.spectra[m.spectrum * NBINS + p.li];
+    const double lambda = (double)p.li * 5.0 + 360.0;
+    if (!outside) {
+        if (m.kind == MAT_EMISSIVE) { value = sv; return SHADE_DONE; }
+        if (m.kind != MAT_DIELECTRIC) return SHADE_DONE;
+        const double l = lambda / 1000.0;
+        const double ior = (m.ior_kind == 0) ? m.ior_a : m.ior_a + m.ior_b / (l * l);
+        const double qx = hx + nx * 10000.0 * EPS64, qy = hy + ny * 10000.0 * EPS64;
+        const double mx = -nx, my = -ny;
+        // glam refract(self = dir, normal = -n, eta = ior)
+        const double ndi = mx * p.dx + my * p.dy;
+        const double kk = 1.0 - ior * ior * (1.0 - ndi * ndi);
+        double rx, ry;
+        bool tir = true;
+        if (kk >= 0.0) {
+            const double mm = ior * ndi + __builtin_sqrt(kk);
+            rx = ior * p.dx - mm * mx;
+            ry = ior * p.dy - mm * my;
+            tir = (rx == 0.0 && ry == 0.0);
+        }
+        if (tir) {
+            const double k2 = 2.0 * (p.dx * mx + p.dy * my);
+            rx = p.dx - k2 * mx;
+            ry = p.dy - k2 * my;
+        }
+        p.thr = p.thr * expf_fixed((float)(-h.t) * sv);
+        p.ox = qx; p.oy = qy; p.dx = rx; p.dy = ry;
+        p.depth_left -= 1;
+        return SHADE_CONTINUE;
+    }
+    switch (m.kind) {
+    case MAT_DIFFUSE: {
+        if (m.black) return SHADE_DONE;
+        const double qx = hx + nx * 10000.0 * EPS64, qy = hy + ny * 10000.0 * EPS64;
+        const uint32_t bounce = (uint32_t)(recursion_limit - p.depth_left);
+        double vx, vy;
+        for (uint32_t attempt = 0;; ++attempt) {
+            const U4 w = philox4x32_10(p.c0, p.c1, p.c2, (bounce << 20) | (attempt & 0xFFFFFu), k0, k1);
+            vx = u01(w.x, w.y) * 2.0 - 1.0;
+            vy = u01(w.z, w.w) * 2.0 - 1.0;
+            if (vx * vx + vy * vy <= 1.0) {
+                const double rl = rlen2(vx, vy);
+                vx = vx * rl;
+                vy = vy * rl;
+                if (vx * nx + vy * ny > 0.0) break;
+            }
+        }
+        p.thr = p.thr * sv;
+        p.ox = qx; p.oy = qy; p.dx = vx; p.dy = vy;
+        p.depth_left -= 1;
+        return SHADE_CONTINUE;
+    }
+    case MAT_EMISSIVE:
+        value = sv;
+        return SHADE_DONE;
+    case MAT_DIRECTIONAL: {
+        const double mx = -nx, my = -ny;
+        if (p.dx * mx + p.dy * my >= m.angle) {
+            const double coeff = 1.0 / (h.t + m.d);
+            value = sv * (float)coeff;
+        }
+        return SHADE_DONE;
+    }
+    case MAT_REFLECTIVE: {
+        const double qx = hx + nx * 10000.0 * EPS64, qy = hy + ny * 10000.0 * EPS64;
+        const double k2 = 2.0 * (p.dx * nx + p.dy * ny);
+        const double rx = p.dx - k2 * nx, ry = p.dy - k2 * ny;
+        p.ox = qx; p.oy = qy; p.dx = rx; p.dy = ry;
+        p.depth_left -= 1;
+        return SHADE_CONTINUE;
+    }
+    case MAT_DIELECTRIC: {
+        const double l = lambda / 1000.0;
+        const double ior = (m.ior_kind == 0) ? m.ior_a : m.ior_a + m.ior_b / (l * l);
+        const double qx = hx - nx * 100000.0 * EPS64, qy = hy - ny * 100000.0 * EPS64;
+        const double eta = 1.0 / ior;
+        const double ndi = nx * p.dx + ny * p.dy;
+        const double kk = 1.0 - eta * eta * (1.0 - ndi * ndi);
+        double rx, ry;
+        bool tir = true;
+        if (kk >= 0.0) {
+            const double mm = eta * ndi + __builtin_sqrt(kk);
+            rx = eta * p.dx - mm * nx;
+            ry = eta * p.dy - mm * ny;
+            tir = (rx == 0.0 && ry == 0.0);
+        }
+        if (tir) {
+            const double k2 = 2.0 * (p.dx * nx + p.dy * ny);
+            rx = p.dx - k2 * nx;
+            ry = p.dy - k2 * ny;
+        }
+        p.ox = qx; p.oy = qy; p.dx = rx; p.dy = ry;
+        p.depth_left -= 1;
+        return SHADE_CONTINUE;
+    }
+    default:
+        return SHADE_DONE;
+    }
+}
+
+// Primary ray of (pixel, global sample) and the wavelength bin of lambda-sample l
+// (librt2d_reverse.rs:88-94).  Every lambda-sample of one sample re-derives the
+// same jitter and angle from the same counters, so the reference's "one ray for
+// all lambda samples" holds without sharing state between lanes.
+RT_DEV void generate(Path &p, int px, int py, int width, uint32_t gsample, uint32_t l, double px_to_world,
+                     int recursion_limit, uint32_t k0, uint32_t k1)
+{
+    const uint32_t pix = (uint32_t)(width * py + px);
+    const U4 w = philox4x32_10(pix, gsample, 0xFFFFFFFFu, 0u, k0, k1);
+    const U4 w1 = philox4x32_10(pix, gsample, 0xFFFFFFFFu, 1u, k0, k1);
+    double x = ((double)px + u01(w.x, w.y)) - 0.5;
+    double y = ((double)py + u01(w.z, w.w)) - 0.5;
+    p.ox = x * px_to_world;
+    p.oy = y * px_to_world;
+    sincos2pi(u01(w1.x, w1.y), p.dy, p.dx);
+    const uint32_t call = 1u + (l + 2u) / 4u, word = (l + 2u) % 4u;
+    U4 wl = w1;
+    if (call != 1u) wl = philox4x32_10(pix, gsample, 0xFFFFFFFFu, call, k0, k1);
+    const uint32_t r = (word == 0u) ? wl.x : (word == 1u) ? wl.y : (word == 2u) ? wl.z : wl.w;
+    p.li = (int)(((uint64_t)r * (uint64_t)NBINS) >> 32);
+    p.thr = 1.0f;
+    p.depth_left = recursion_limit;
+    p.c0 = pix;
+    p.c1 = gsample;
+    p.c2 = l;
+}
+
+} // namespace rt2d

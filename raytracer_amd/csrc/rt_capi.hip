@@ -1,0 +1,900 @@
+// Host side of the C ABI declared in include/rt_abi.h: argument validation,
+// scene upload (SoA in HBM), kernel launches on the context's stream, timing
+// with HIP events on that stream.  There is no CPU path in this library.
+#include "../../include/rt_abi.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "rt_kernels.hpp"
+
+namespace {
+
+thread_local std::string g_err;
+
+int32_t fail(int32_t code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                      \
+    do {                                                                                                   \
+        hipError_t e_ = (expr);                                                                            \
+        if (e_ != hipSuccess)                                                                              \
+            return fail(e_ == hipErrorOutOfMemory ? RT_E_OOM : RT_E_HIP, "%s failed: %s (%s:%d)", #expr,    \
+                        hipGetErrorString(e_), __FILE__, __LINE__);                                        \
+    } while (0)
+
+// Largest coordinate / direction magnitudes the sign filters of the nearest-hit
+// search are proven for (see rt2d_device.hpp).
+constexpr double MAX_COORD = 0x1.0p40;
+constexpr double MAX_DIR = 0x1.0p20;
+constexpr double MIN_RADIUS = 0x1.0p-400;
+
+bool finite_within(double v, double lim) { return std::isfinite(v) && std::fabs(v) <= lim; }
+
+int refill_threshold(int n_prims)
+{
+    if (const char *e = getenv("RT_REFILL_MIN")) {
+        int v = atoi(e);
+        if (v >= 1 && v <= 64) return v;
+    }
+    // regenerating rays costs about as much as testing ~16 primitives; small
+    // scenes batch the refills, large ones keep every lane busy
+    if (n_prims >= 96) return 1;
+    if (n_prims >= 32) return 8;
+    return 16;
+}
+
+} // namespace
+
+struct rt_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    unsigned long long *d_rays = nullptr;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending; // trace-kernel brackets not yet folded
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> free_events;
+    double kernel_ms = 0.0;
+    uint64_t samples = 0, launches = 0;
+    // grow-only device workspace for the host-pointer entry points
+    void *ws = nullptr;
+    size_t ws_bytes = 0;
+};
+
+struct rt2d_scene {
+    rt_ctx *ctx = nullptr;
+    void *blob = nullptr;
+    rt2d::SceneDev dev{};
+    int n_prims = 0;
+};
+
+struct rt3d_scene {
+    rt_ctx *ctx = nullptr;
+    void *blob = nullptr;
+    rt3d::SceneDev dev{};
+};
+
+namespace {
+
+int32_t ctx_bind(rt_ctx *ctx)
+{
+    if (!ctx) return fail(RT_E_INVALID, "null context");
+    HIP_TRY(hipSetDevice(ctx->device));
+    return RT_OK;
+}
+
+int32_t ctx_workspace(rt_ctx *ctx, size_t bytes, void **out)
+{
+    if (bytes > ctx->ws_bytes) {
+        if (ctx->ws) {
+            HIP_TRY(hipStreamSynchronize(ctx->stream));
+            HIP_TRY(hipFree(ctx->ws));
+            ctx->ws = nullptr;
+            ctx->ws_bytes = 0;
+        }
+        const size_t want = bytes + bytes / 8 + 4096;
+        HIP_TRY(hipMalloc(&ctx->ws, want));
+        ctx->ws_bytes = want;
+    }
+    *out = ctx->ws;
+    return RT_OK;
+}
+
+int32_t event_pair(rt_ctx *ctx, std::pair<hipEvent_t, hipEvent_t> *ev)
+{
+    if (!ctx->free_events.empty()) {
+        *ev = ctx->free_events.back();
+        ctx->free_events.pop_back();
+        return RT_OK;
+    }
+    HIP_TRY(hipEventCreate(&ev->first));
+    HIP_TRY(hipEventCreate(&ev->second));
+    return RT_OK;
+}
+
+// Fold finished event brackets into kernel_ms.  Keeps at most `keep` pending.
+int32_t fold_events(rt_ctx *ctx, size_t keep)
+{
+    while (ctx->pending.size() > keep) {
+        auto ev = ctx->pending.front();
+        HIP_TRY(hipEventSynchronize(ev.second));
+        float ms = 0.0f;
+        HIP_TRY(hipEventElapsedTime(&ms, ev.first, ev.second));
+        ctx->kernel_ms += (double)ms;
+        ctx->pending.erase(ctx->pending.begin());
+        ctx->free_events.push_back(ev);
+    }
+    return RT_OK;
+}
+
+struct Carver {
+    char *base;
+    size_t off = 0;
+    template <typename T> T *take(size_t n)
+    {
+        off = (off + 255) & ~size_t(255);
+        T *p = base ? reinterpret_cast<T *>(base + off) : nullptr;
+        off += n * sizeof(T);
+        return p;
+    }
+};
+
+} // namespace
+
+extern "C" {
+
+const char *rt_version(void) { return "raytracer_amd 0.1 (gfx950)"; }
+
+const char *rt_last_error(void) { return g_err.c_str(); }
+
+int32_t rt_device_count(int32_t *count)
+{
+    if (!count) return fail(RT_E_INVALID, "null count");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *count = 0;
+        return fail(RT_E_NO_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e));
+    }
+    *count = n;
+    return RT_OK;
+}
+
+int32_t rt_ctx_create(int32_t device_id, rt_ctx **out)
+{
+    if (!out) return fail(RT_E_INVALID, "null out");
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        return fail(RT_E_NO_DEVICE, "no HIP device visible; this library has no CPU path");
+    if (device_id < 0 || device_id >= n) return fail(RT_E_INVALID, "device %d out of range (0..%d)", device_id, n - 1);
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device_id));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(RT_E_NO_DEVICE, "device %d is %s; the kernels are built for gfx950 only", device_id, prop.gcnArchName);
+    HIP_TRY(hipSetDevice(device_id));
+    rt_ctx *ctx = new (std::nothrow) rt_ctx();
+    if (!ctx) return fail(RT_E_OOM, "host allocation failed");
+    ctx->device = device_id;
+    HIP_TRY(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
+    ctx->stream = ctx->own_stream;
+    HIP_TRY(hipMalloc((void **)&ctx->d_rays, sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(ctx->d_rays, 0, sizeof(unsigned long long)));
+    *out = ctx;
+    return RT_OK;
+}
+
+int32_t rt_ctx_destroy(rt_ctx *ctx)
+{
+    if (!ctx) return RT_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto &ev : ctx->pending) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+    for (auto &ev : ctx->free_events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+    if (ctx->ws) (void)hipFree(ctx->ws);
+    if (ctx->d_rays) (void)hipFree(ctx->d_rays);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+    return RT_OK;
+}
+
+int32_t rt_ctx_set_stream(rt_ctx *ctx, void *hip_stream)
+{
+    if (int32_t rc = ctx_bind(ctx)) return rc;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return RT_OK;
+}
+
+int32_t rt_ctx_synchronize(rt_ctx *ctx)
+{
+    if (int32_t rc = ctx_bind(ctx)) return rc;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return RT_OK;
+}
+
+int32_t rt_ctx_get_stats(rt_ctx *ctx, rt_stats *out)
+{
+    if (int32_t rc = ctx_bind(ctx)) return rc;
+    if (!out) return fail(RT_E_INVALID, "null out");
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (int32_t rc = fold_events(ctx, 0)) return rc;
+    unsigned long long rays = 0;
+    HIP_TRY(hipMemcpy(&rays, ctx->d_rays, sizeof rays, hipMemcpyDeviceToHost));
+    out->rays = rays;
+    out->samples = ctx->samples;
+    out->launches = ctx->launches;
+    out->kernel_ms = ctx->kernel_ms;
+    return RT_OK;
+}
+
+int32_t rt_ctx_reset_stats(rt_ctx *ctx)
+{
+    if (int32_t rc = ctx_bind(ctx)) return rc;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (int32_t rc = fold_events(ctx, 0)) return rc;
+    HIP_TRY(hipMemset(ctx->d_rays, 0, sizeof(unsigned long long)));
+    ctx->kernel_ms = 0.0;
+    ctx->samples = 0;
+    ctx->launches = 0;
+    return RT_OK;
+}
+
+// ---------------------------------------------------------------------------
+// 2d scene
+int32_t rt2d_scene_create(rt_ctx *ctx, const rt2d_scene_desc *d, rt2d_scene **out)
+{
+    if (int32_t rc = ctx_bind(ctx)) return rc;
+    if (!d || !out) return fail(RT_E_INVALID, "null argument");
+    *out = nullptr;
+    const int nc = d->n_circles, ns = d->n_segments, no = d->n_objects, nsp = d->n_spectra;
+    if (nc < 0 || ns < 0 || no < 0 || nsp < 0) return fail(RT_E_INVALID, "negative count");
+    if ((int64_t)nc + ns > (1 << 20)) return fail(RT_E_LIMIT, "more than 2^20 primitives");
+    if (nc && !(d->circle_cx && d->circle_cy && d->circle_r && d->circle_obj && d->circle_pid))
+        return fail(RT_E_INVALID, "null circle array");
+    if (ns && !(d->seg_ax && d->seg_ay && d->seg_bx && d->seg_by && d->seg_nx && d->seg_ny && d->seg_obj && d->seg_pid))
+        return fail(RT_E_INVALID, "null segment array");
+    if (no && !d->materials) return fail(RT_E_INVALID, "null materials");
+    if (nsp && !d->spectra) return fail(RT_E_INVALID, "null spectra");
+    const int P = nc + ns;
+    std::vector<char> seen((size_t)std::max(P, 1), 0);
+    auto check_pid = [&](int pid) {
+        if (pid < 0 || pid >= P || seen[(size_t)pid]) return false;
+        seen[(size_t)pid] = 1;
+        return true;
+    };
+    for (int i = 0; i < nc; ++i) {
+        if (!finite_within(d->circle_cx[i], MAX_COORD) || !finite_within(d->circle_cy[i], MAX_COORD) ||
+            !finite_within(d->circle_r[i], MAX_COORD) || std::fabs(d->circle_r[i]) < MIN_RADIUS)
+            return fail(RT_E_INVALID, "circle %d: coordinates must be finite, |v| <= 2^40, |r| >= 2^-400", i);
+        if (d->circle_obj[i] < 0 || d->circle_obj[i] >= no) return fail(RT_E_INVALID, "circle %d: object out of range", i);
+        if (!check_pid(d->circle_pid[i])) return fail(RT_E_INVALID, "circle %d: pid out of range or repeated", i);
+    }
+    for (int i = 0; i < ns; ++i) {
+        const double v[6] = { d->seg_ax[i], d->seg_ay[i], d->seg_bx[i], d->seg_by[i], d->seg_nx[i], d->seg_ny[i] };
+        for (double x : v)
+            if (!finite_within(x, MAX_COORD)) return fail(RT_E_INVALID, "segment %d: values must be finite, |v| <= 2^40", i);
+        if (d->seg_obj[i] < 0 || d->seg_obj[i] >= no) return fail(RT_E_INVALID, "segment %d: object out of range", i);
+        if (!check_pid(d->seg_pid[i])) return fail(RT_E_INVALID, "segment %d: pid out of range or repeated", i);
+    }
+    for (int i = 0; i < no; ++i) {
+        const rt2d_material &m = d->materials[i];
+        if (m.kind < RT_MAT_EMISSIVE || m.kind > RT_MAT_DIELECTRIC) return fail(RT_E_INVALID, "object %d: unknown material %d", i, m.kind);
+        if (m.kind != RT_MAT_REFLECTIVE && (m.spectrum < 0 || m.spectrum >= nsp))
+            return fail(RT_E_INVALID, "object %d: spectrum row out of range", i);
+        if (m.kind == RT_MAT_DIELECTRIC && (m.ior_kind < 0 || m.ior_kind > 1)) return fail(RT_E_INVALID, "object %d: unknown ior kind", i);
+    }
+
+    // slot order: circles by pid, then segments by pid
+    std::vector<int> corder((size_t)nc), sorder((size_t)ns);
+    for (int i = 0; i < nc; ++i) corder[(size_t)i] = i;
+    for (int i = 0; i < ns; ++i) sorder[(size_t)i] = i;
+    std::sort(corder.begin(), corder.end(), [&](int a, int b) { return d->circle_pid[a] < d->circle_pid[b]; });
+    std::sort(sorder.begin(), sorder.end(), [&](int a, int b) { return d->seg_pid[a] < d->seg_pid[b]; });
+
+    Carver sz{ nullptr };
+    auto layout = [&](Carver &c, rt2d::SceneDev &S, std::vector<char> *host) {
+        double *ccx = c.take<double>(nc), *ccy = c.take<double>(nc), *cr2 = c.take<double>(nc);
+        double *sax = c.take<double>(ns), *say = c.take<double>(ns), *ssx = c.take<double>(ns), *ssy = c.take<double>(ns);
+        double *snx = c.take<double>(ns), *sny = c.take<double>(ns);
+        int32_t *cobj = c.take<int32_t>(nc), *cpid = c.take<int32_t>(nc), *sobj = c.take<int32_t>(ns), *spid = c.take<int32_t>(ns);
+        rt2d::MatDev *mats = c.take<rt2d::MatDev>(no);
+        float *spectra = c.take<float>((size_t)nsp * RT_NBINS);
+        if (host) {
+            char *hb = host->data();
+            auto H = [&](auto *p) { return reinterpret_cast<decltype(p)>(hb + (reinterpret_cast<char *>(p) - c.base)); };
+            for (int k = 0; k < nc; ++k) {
+                const int i = corder[(size_t)k];
+                H(ccx)[k] = d->circle_cx[i];
+                H(ccy)[k] = d->circle_cy[i];
+                H(cr2)[k] = d->circle_r[i] * d->circle_r[i]; // r.powi(2), rt_common.rs:76,83
+                H(cobj)[k] = d->circle_obj[i];
+                H(cpid)[k] = d->circle_pid[i];
+            }
+            for (int k = 0; k < ns; ++k) {
+                const int i = sorder[(size_t)k];
+                H(sax)[k] = d->seg_ax[i];
+                H(say)[k] = d->seg_ay[i];
+                H(ssx)[k] = d->seg_bx[i] - d->seg_ax[i]; // s = b - a, rt_common.rs:244
+                H(ssy)[k] = d->seg_by[i] - d->seg_ay[i];
+                H(snx)[k] = d->seg_nx[i];
+                H(sny)[k] = d->seg_ny[i];
+                H(sobj)[k] = d->seg_obj[i];
+                H(spid)[k] = d->seg_pid[i];
+            }
+            for (int i = 0; i < no; ++i) {
+                const rt2d_material &m = d->materials[i];
+                rt2d::MatDev md{};
+                md.kind = m.kind; md.ior_kind = m.ior_kind;
+                md.ior_a = m.ior_a; md.ior_b = m.ior_b; md.angle = m.angle; md.d = m.d;
+                md.spectrum = (m.kind == RT_MAT_REFLECTIVE) ? 0 : m.spectrum;
+                md.black = 0;
+                if (m.kind == RT_MAT_DIFFUSE) {
+                    bool all_zero = true;
+                    for (int b = 0; b < RT_NBINS; ++b)
+                        if (d->spectra[(size_t)m.spectrum * RT_NBINS + b] != 0.0f) all_zero = false;
+                    md.black = all_zero ? 1 : 0;
+                }
+                H(mats)[i] = md;
+            }
+            if (nsp) memcpy(H(spectra), d->spectra, sizeof(float) * (size_t)nsp * RT_NBINS);
+        }
+        S.n_circ = nc; S.n_seg = ns; S.n_obj = no; S.pad_ = 0;
+        S.ccx = ccx; S.ccy = ccy; S.cr2 = cr2;
+        S.sax = sax; S.say = say; S.ssx = ssx; S.ssy = ssy; S.snx = snx; S.sny = sny;
+        S.cobj = cobj; S.cpid = cpid; S.sobj = sobj; S.spid = spid;
+        S.mats = mats; S.spectra = spectra;
+    };
+    rt2d::SceneDev tmp{};
+    layout(sz, tmp, nullptr);
+    const size_t bytes = sz.off + 256;
+
+    rt2d_scene *sc = new (std::nothrow) rt2d_scene();
+    if (!sc) return fail(RT_E_OOM, "host allocation failed");
+    sc->ctx = ctx;
+    sc->n_prims = P;
+    hipError_t e = hipMalloc(&sc->blob, bytes);
+    if (e != hipSuccess) {
+        delete sc;
+        return fail(RT_E_OOM, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e));
+    }
+    std::vector<char> host(bytes, 0);
+    Carver dc{ reinterpret_cast<char *>(sc->blob) };
+    layout(dc, sc->dev, &host);
+    e = hipMemcpy(sc->blob, host.data(), bytes, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        (void)hipFree(sc->blob);
+        delete sc;
+        return fail(RT_E_HIP, "scene upload: %s", hipGetErrorString(e));
+    }
+    *out = sc;
+    return RT_OK;
+}
+
+int32_t rt2d_scene_destroy(rt2d_scene *scene)
+{
+    if (!scene) return RT_OK;
+    (void)hipSetDevice(scene->ctx->device);
+    (void)hipStreamSynchronize(scene->ctx->stream);
+    if (scene->blob) (void)hipFree(scene->blob);
+    delete scene;
+    return RT_OK;
+}
+
+} // extern "C"
+
+namespace {
+
+int32_t check_params2d(const rt2d_render_params *p)
+{
+    if (!p) return fail(RT_E_INVALID, "null params");
+    if (p->width <= 0 || p->height <= 0) return fail(RT_E_INVALID, "image size must be positive");
+    if (p->spp <= 0 || p->lambda_samples <= 0) return fail(RT_E_INVALID, "spp and lambda_samples must be positive");
+    if (p->recursion_limit < 0 || p->recursion_limit > 4095) return fail(RT_E_LIMIT, "recursion_limit must be in 0..4095");
+    if ((int64_t)p->spp * p->lambda_samples > (1 << 24)) return fail(RT_E_LIMIT, "spp * lambda_samples must be <= 2^24 per call");
+    if (p->sample_offset < 0 || (int64_t)p->sample_offset + p->spp > 0x7fffffffLL) return fail(RT_E_INVALID, "sample range out of bounds");
+    if ((int64_t)p->width * p->height > (1LL << 30)) return fail(RT_E_LIMIT, "image larger than 2^30 pixels");
+    if (!std::isfinite(p->px_to_world) || p->px_to_world <= 0.0 ||
+        (double)std::max(p->width, p->height) * p->px_to_world > MAX_COORD)
+        return fail(RT_E_INVALID, "px_to_world must be finite, positive and keep the image inside |v| <= 2^40");
+    return RT_OK;
+}
+
+int32_t launch_render2d(rt_ctx *ctx, const rt2d_scene *scene, const rt2d_render_params *p, int list_mode, int64_t n_list,
+                        const int32_t *d_px, const int32_t *d_py, float *d_out)
+{
+    rtk::Render2dArgs A{};
+    A.S = scene->dev;
+    A.width = p->width; A.height = p->height; A.spp = p->spp; A.lambda_samples = p->lambda_samples;
+    A.recursion_limit = p->recursion_limit; A.sample_offset = p->sample_offset;
+    A.k0 = (uint32_t)p->seed; A.k1 = (uint32_t)(p->seed >> 32);
+    A.px_to_world = p->px_to_world;
+    A.list_mode = list_mode;
+    A.tiles_x = (p->width + 7) / 8;
+    A.list_px = d_px; A.list_py = d_py; A.n_list = n_list;
+    A.out = d_out;
+    A.ray_counter = ctx->d_rays;
+    A.refill_min = refill_threshold(scene->n_prims);
+    int64_t tiles = list_mode ? (n_list + rtk::TILE_PIXELS - 1) / rtk::TILE_PIXELS
+                              : (int64_t)A.tiles_x * ((p->height + 7) / 8);
+    if (tiles <= 0) return RT_OK;
+    if (tiles > 0x7fffffffLL) return fail(RT_E_LIMIT, "too many tiles");
+    std::pair<hipEvent_t, hipEvent_t> ev;
+    if (int32_t rc = fold_events(ctx, 256)) return rc;
+    if (int32_t rc = event_pair(ctx, &ev)) return rc;
+    HIP_TRY(hipEventRecord(ev.first, ctx->stream));
+    hipLaunchKernelGGL(rtk::render2d_kernel, dim3((unsigned)tiles), dim3(rtk::BLOCK), 0, ctx->stream, A);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(ev.second, ctx->stream));
+    ctx->pending.push_back(ev);
+    ctx->launches += 1;
+    const int64_t npx = list_mode ? n_list : (int64_t)p->width * p->height;
+    ctx->samples += (uint64_t)npx * (uint64_t)p->spp * (uint64_t)p->lambda_samples;
+    return RT_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int32_t rt2d_accumulate(rt_ctx *ctx, const rt2d_scene *scene, const rt2d_render_params *p, void *d_spectrum)
+{
+    if (int32_t rc = ctx_bind(ctx)) return rc;
+    if (!scene || scene->ctx != ctx) return fail(RT_E_INVALID, "scene does not belong to this context");
+    if (int32_t rc = check_params2d(p)) return rc;
+    if (!d_spectrum) return fail(RT_E_INVALID, "null d_spectrum");
+    return launch_render2d(ctx, scene, p, 0, 0, nullptr, nullptr, (float *)d_spectrum);
+}
+
+int32_t rt2d_resolve(rt_ctx *ctx, const void *d_spectrum, int32_t width, int32_t height, int32_t total_spp, void *d_rgb,
+                     float *out_rgb, float *out_weight)
+{
+    if (int32_t rc = ctx_bind(ctx)) return rc;
+    if (!d_spectrum) return fail(RT_E_INVALID, "null d_spectrum");
+    if (width <= 0 || height <= 0 || total_spp <= 0) return fail(RT_E_INVALID, "sizes must be positive");
+    const int64_t npx = (int64_t)width * height;
+    float *rgb = (float *)d_rgb;
+    float *w = nullptr;
+    if (!rgb || out_weight) {
+        void *ws = nullptr;
+        if (int32_t rc = ctx_workspace(ctx, (size_t)npx * 4 * sizeof(float), &ws)) return rc;
+        if (!rgb) rgb = (float *)ws;
+        w = (float *)ws + npx * 3;
+    }
+    const unsigned blocks = (unsigned)((npx + 63) / 64);
+    hipLaunchKernelGGL(rtk::resolve2d_kernel, dim3(blocks), dim3(64), 0, ctx->stream, (const float *)d_spectrum, npx,
+                       (float)total_spp, rgb, out_weight ? w : nullptr);
+    HIP_TRY(hipGetLastError());
+    if (out_rgb) HIP_TRY(hipMemcpyAsync(out_rgb, rgb, (size_t)npx * 3 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    if (out_weight) HIP_TRY(hipMemcpyAsync(out_weight, w, (size_t)npx * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    if (out_rgb || out_weight) HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return RT_OK;
+}
+
+int32_t rt2d_render(rt_ctx *ctx, const rt2d_scene *scene, const rt2d_render_params *p, float *out_rgb, float *out_weight,
+                    float *out_spectrum)
+{
+    if (int32_t rc = ctx_bind(ctx)) return rc;
+    if (!scene || scene->ctx != ctx) return fail(RT_E_INVALID, "scene does not belong to this context");
+    if (int32_t rc = check_params2d(p)) return rc;
+    const int64_t npx = (int64_t)p->width * p->height;
+    // a dedicated accumulation buffer: the shared workspace is used by resolve
+    float *d_spec = nullptr;
+    HIP_TRY(hipMalloc((void **)&d_spec, (size_t)npx * RT_NBINS * sizeof(float)));
+    int32_t rc = RT_OK;
+    hipError_t e = hipMemsetAsync(d_spec, 0, (size_t)npx * RT_NBINS * sizeof(float), ctx->stream);
+    if (e != hipSuccess) rc = fail(RT_E_HIP, "memset: %s", hipGetErrorString(e));
+    if (!rc) rc = launch_render2d(ctx, scene, p, 0, 0, nullptr, nullptr, d_spec);
+    if (!rc && (out_rgb || out_weight)) rc = rt2d_resolve(ctx, d_spec, p->width, p->height, p->spp, nullptr, out_rgb, out_weight);
+    if (!rc && out_spectrum) {
+        // compute_pixel's return value = accumulated / spp; divide on the host copy
+        e = hipMemcpyAsync(out_spectrum, d_spec, (size_t)npx * RT_NBINS * sizeof(float), hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) rc = fail(RT_E_HIP, "spectrum download: %s", hipGetErrorString(e));
+        else {
+            const float spp = (float)p->spp;
+            for (int64_t i = 0; i < npx * RT_NBINS; ++i) out_spectrum[i] = out_spectrum[i] / spp;
+        }
+    }
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d_spec);
+    return rc;
+}
+
+int32_t rt2d_compute_pixels(rt_ctx *ctx, const rt2d_scene *scene, const rt2d_render_params *p, int64_t n, const int32_t *px,
+                            const int32_t *py, float *out_spectrum)
+{
+    if (int32_t rc = ctx_bind(ctx)) return rc;
+    if (!scene || scene->ctx != ctx) return fail(RT_E_INVALID, "scene does not belong to this context");
+    if (int32_t rc = check_params2d(p)) return rc;
+    if (n < 0) return fail(RT_E_INVALID, "negative n");
+    if (n == 0) return RT_OK;
+    if (!px || !py || !out_spectrum) return fail(RT_E_INVALID, "null argument");
+    if (n > (1LL << 30)) return fail(RT_E_LIMIT, "more than 2^30 pixels");
+    for (int64_t k = 0; k < n; ++k) {
+        const double lim = MAX_COORD / p->px_to_world;
+        if (std::fabs((double)px[k]) > lim || std::fabs((double)py[k]) > lim)
+            return fail(RT_E_INVALID, "pixel %lld maps outside |v| <= 2^40", (long long)k);
+    }
+    Carver c{ nullptr };
+    c.take<int32_t>((size_t)n); c.take<int32_t>((size_t)n); c.take<float>((size_t)n * RT_NBINS);
+    void *ws = nullptr;
+    if (int32_t rc = ctx_workspace(ctx, c.off + 256, &ws)) return rc;
+    Carver w{ (char *)ws };
+    int32_t *d_px = w.take<int32_t>((size_t)n), *d_py = w.take<int32_t>((size_t)n);
+    float *d_out = w.take<float>((size_t)n * RT_NBINS);
+    HIP_TRY(hipMemcpyAsync(d_px, px, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(d_py, py, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    if (int32_t rc = launch_render2d(ctx, scene, p, 1, n, d_px, d_py, d_out)) return rc;
+    HIP_TRY(hipMemcpyAsync(out_spectrum, d_out, sizeof(float) * (size_t)n * RT_NBINS, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return RT_OK;
+}
+
+int32_t rt2d_trace_batch(rt_ctx *ctx, const rt2d_scene *scene, int64_t n, const double *ox, const double *oy, const double *dx,
+                         const double *dy, const int32_t *lambda_idx, int32_t depth, uint64_t seed, float *radiance,
+                         int32_t *first_prim, double *first_t, int32_t *bounces)
+{
+    if (int32_t rc = ctx_bind(ctx)) return rc;
+    if (!scene || scene->ctx != ctx) return fail(RT_E_INVALID, "scene does not belong to this context");
+    if (n < 0) return fail(RT_E_INVALID, "negative n");
+    if (n == 0) return RT_OK;
+    if (!ox || !oy || !dx || !dy || !lambda_idx || !radiance) return fail(RT_E_INVALID, "null argument");
+    if (depth < 0 || depth > 4095) return fail(RT_E_LIMIT, "depth must be in 0..4095");
+    if (n > (1LL << 31) * rtk::BLOCK) return fail(RT_E_LIMIT, "batch too large");
+    for (int64_t i = 0; i < n; ++i) {
+        if (!finite_within(ox[i], MAX_COORD) || !finite_within(oy[i], MAX_COORD) || !finite_within(dx[i], MAX_DIR) ||
+            !finite_within(dy[i], MAX_DIR))
+            return fail(RT_E_INVALID, "ray %lld: origin must be finite with |v| <= 2^40, direction with |v| <= 2^20", (long long)i);
+        if (lambda_idx[i] < 0 || lambda_idx[i] >= RT_NBINS) return fail(RT_E_INVALID, "ray %lld: lambda_idx out of 0..94", (long long)i);
+    }
+    Carver c{ nullptr };
+    for (int k = 0; k < 5; ++k) c.take<double>((size_t)n);
+    c.take<int32_t>((size_t)n); c.take<int32_t>((size_t)n); c.take<int32_t>((size_t)n); c.take<float>((size_t)n);
+    void *ws = nullptr;
+    if (int32_t rc = ctx_workspace(ctx, c.off + 256, &ws)) return rc;
+    Carver w{ (char *)ws };
+    double *d_ox = w.take<double>((size_t)n), *d_oy = w.take<double>((size_t)n), *d_dx = w.take<double>((size_t)n);
+    double *d_dy = w.take<double>((size_t)n), *d_ft = w.take<double>((size_t)n);
+    int32_t *d_li = w.take<int32_t>((size_t)n), *d_fp = w.take<int32_t>((size_t)n), *d_nb = w.take<int32_t>((size_t)n);
+    float *d_rad = w.take<float>((size_t)n);
+    const size_t nb8 = sizeof(double) * (size_t)n, nb4 = sizeof(int32_t) * (size_t)n;
+    HIP_TRY(hipMemcpyAsync(d_ox, ox, nb8, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(d_oy, oy, nb8, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(d_dx, dx, nb8, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(d_dy, dy, nb8, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(d_li, lambda_idx, nb4, hipMemcpyHostToDevice, ctx->stream));
+    std::pair<hipEvent_t, hipEvent_t> ev;
+    if (int32_t rc = fold_events(ctx, 256)) return rc;
+    if (int32_t rc = event_pair(ctx, &ev)) return rc;
+    HIP_TRY(hipEventRecord(ev.first, ctx->stream));
+    const unsigned blocks = (unsigned)((n + rtk::BLOCK - 1) / rtk::BLOCK);
+    hipLaunchKernelGGL(rtk::trace_batch2d_kernel, dim3(blocks), dim3(rtk::BLOCK), 0, ctx->stream, scene->dev, n, d_ox, d_oy, d_dx,
+                       d_dy, d_li, depth, (uint32_t)seed, (uint32_t)(seed >> 32), d_rad, d_fp, d_ft, d_nb, ctx->d_rays);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(ev.second, ctx->stream));
+    ctx->pending.push_back(ev);
+    ctx->launches += 1;
+    ctx->samples += (uint64_t)n;
+    HIP_TRY(hipMemcpyAsync(radiance, d_rad, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    if (first_prim) HIP_TRY(hipMemcpyAsync(first_prim, d_fp, nb4, hipMemcpyDeviceToHost, ctx->stream));
+    if (first_t) HIP_TRY(hipMemcpyAsync(first_t, d_ft, nb8, hipMemcpyDeviceToHost, ctx->stream));
+    if (bounces) HIP_TRY(hipMemcpyAsync(bounces, d_nb, nb4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return RT_OK;
+}
+
+// ---------------------------------------------------------------------------
+// 3d
+} // extern "C"
+
+namespace {
+
+struct BuildSphere { double c[3], r; int sid; };
+
+// Median-split BVH over sphere boxes; children of a node are adjacent; leaves hold <= 2 spheres.
+struct BvhBuilder {
+    std::vector<BuildSphere> &sp; // tree spheres, reordered in place into leaf order
+    std::vector<rt3d::BvhNode> nodes;
+    int max_depth = 0;
+    double pad;
+    explicit BvhBuilder(std::vector<BuildSphere> &s, double pad_) : sp(s), pad(pad_) {}
+
+    void bounds(int first, int count, rt3d::BvhNode &nd)
+    {
+        for (int a = 0; a < 3; ++a) { nd.lo[a] = INFINITY; nd.hi[a] = -INFINITY; }
+        for (int i = first; i < first + count; ++i)
+            for (int a = 0; a < 3; ++a) {
+                nd.lo[a] = std::min(nd.lo[a], sp[(size_t)i].c[a] - std::fabs(sp[(size_t)i].r));
+                nd.hi[a] = std::max(nd.hi[a], sp[(size_t)i].c[a] + std::fabs(sp[(size_t)i].r));
+            }
+        for (int a = 0; a < 3; ++a) { nd.lo[a] -= pad; nd.hi[a] += pad; }
+    }
+
+    void build(int node, int first, int count, int depth)
+    {
+        max_depth = std::max(max_depth, depth);
+        rt3d::BvhNode nd{};
+        bounds(first, count, nd);
+        if (count <= 2) {
+            nd.left = first; nd.count = count; nd.axis = 0;
+            nodes[(size_t)node] = nd;
+            return;
+        }
+        double clo[3] = { INFINITY, INFINITY, INFINITY }, chi[3] = { -INFINITY, -INFINITY, -INFINITY };
+        for (int i = first; i < first + count; ++i)
+            for (int a = 0; a < 3; ++a) { clo[a] = std::min(clo[a], sp[(size_t)i].c[a]); chi[a] = std::max(chi[a], sp[(size_t)i].c[a]); }
+        int axis = 0;
+        for (int a = 1; a < 3; ++a) if (chi[a] - clo[a] > chi[axis] - clo[axis]) axis = a;
+        const int mid = first + count / 2;
+        std::nth_element(sp.begin() + first, sp.begin() + mid, sp.begin() + first + count,
+                         [axis](const BuildSphere &x, const BuildSphere &y) {
+                             return x.c[axis] < y.c[axis] || (x.c[axis] == y.c[axis] && x.sid < y.sid);
+                         });
+        const int left = (int)nodes.size();
+        nodes.emplace_back();
+        nodes.emplace_back();
+        nd.left = left; nd.count = 0; nd.axis = axis;
+        nodes[(size_t)node] = nd;
+        build(left, first, mid - first, depth + 1);
+        build(left + 1, mid, first + count - mid, depth + 1);
+    }
+};
+
+} // namespace
+
+extern "C" {
+
+int32_t rt3d_scene_create(rt_ctx *ctx, const rt3d_scene_desc *d, rt3d_scene **out)
+{
+    if (int32_t rc = ctx_bind(ctx)) return rc;
+    if (!d || !out) return fail(RT_E_INVALID, "null argument");
+    *out = nullptr;
+    const int n = d->n_spheres;
+    if (n < 0) return fail(RT_E_INVALID, "negative count");
+    if (n > (1 << 24)) return fail(RT_E_LIMIT, "more than 2^24 spheres");
+    if (n && !(d->cx && d->cy && d->cz && d->r)) return fail(RT_E_INVALID, "null sphere array");
+    if (d->width <= 0 || d->height <= 0 || (int64_t)d->width * d->height > (1LL << 30)) return fail(RT_E_INVALID, "bad image size");
+    for (int i = 0; i < n; ++i)
+        if (!finite_within(d->cx[i], MAX_COORD) || !finite_within(d->cy[i], MAX_COORD) || !finite_within(d->cz[i], MAX_COORD) ||
+            !finite_within(d->r[i], MAX_COORD))
+            return fail(RT_E_INVALID, "sphere %d: values must be finite with |v| <= 2^40", i);
+    for (int a = 0; a < 3; ++a)
+        if (!finite_within(d->cam_pos[a], MAX_COORD) || !std::isfinite(d->cam_dir[a]) || !std::isfinite(d->cam_up[a]))
+            return fail(RT_E_INVALID, "camera vectors must be finite");
+    if (!std::isfinite(d->focal_length)) return fail(RT_E_INVALID, "focal_length must be finite");
+    // Camera::new, 3d/src/rt.rs:139-178 (its two asserts become an error return)
+    auto dot = [](const double *a, const double *b) { return (a[0] * b[0]) + (a[1] * b[1]) + (a[2] * b[2]); };
+    const double *pos = d->cam_pos, *dir = d->cam_dir, *up = d->cam_up;
+    if (!(std::fabs(dot(dir, dir) - 1.0) <= 2e-4) || !(std::fabs(dot(up, up) - 1.0) <= 2e-4))
+        return fail(RT_E_INVALID, "camera dir and up must be normalized (|len^2 - 1| <= 2e-4)");
+    rt3d::SceneDev S{};
+    {
+        const double vh = 2.0;
+        const double vw = vh * ((double)d->width / (double)d->height);
+        const double right[3] = { dir[1] * up[2] - up[1] * dir[2], dir[2] * up[0] - up[2] * dir[0], dir[0] * up[1] - up[0] * dir[1] };
+        for (int a = 0; a < 3; ++a) {
+            const double vu = right[a] * vw, vv = up[a] * vh;
+            S.du[a] = vu / (double)d->width;
+            S.dv[a] = vv / (double)d->height;
+            const double ul = ((pos[a] + d->focal_length * dir[a]) - vu / 2.0) - vv / 2.0;
+            S.p00[a] = ul + (S.du[a] + S.dv[a]) / 2.0;
+            S.pos[a] = pos[a];
+        }
+    }
+    S.n = n; S.width = d->width; S.height = d->height; S.use_bvh = d->use_bvh ? 1 : 0;
+
+    std::vector<BuildSphere> always, tree;
+    std::vector<rt3d::BvhNode> nodes;
+    if (S.use_bvh && n > 0) {
+        std::vector<double> radii((size_t)n);
+        for (int i = 0; i < n; ++i) radii[(size_t)i] = std::fabs(d->r[i]);
+        std::nth_element(radii.begin(), radii.begin() + n / 2, radii.end());
+        const double r_med = radii[(size_t)(n / 2)];
+        for (int i = 0; i < n; ++i) {
+            BuildSphere b{ { d->cx[i], d->cy[i], d->cz[i] }, d->r[i], i };
+            // a sphere far larger than the rest would swallow every box above it: test it on every ray instead
+            if (std::fabs(d->r[i]) > 64.0 * r_med && always.size() < 32) always.push_back(b);
+            else tree.push_back(b);
+        }
+        if (!tree.empty()) {
+            double scale = 1.0;
+            for (const BuildSphere &b : tree)
+                for (int a = 0; a < 3; ++a) scale = std::max(scale, std::fabs(b.c[a]) + std::fabs(b.r));
+            BvhBuilder bb(tree, 1e-7 * scale);
+            bb.nodes.emplace_back();
+            bb.build(0, 0, (int)tree.size(), 1);
+            if (bb.max_depth > rt3d::BVH_STACK) return fail(RT_E_LIMIT, "BVH deeper than %d levels", rt3d::BVH_STACK);
+            nodes.swap(bb.nodes);
+            // leaf ranges index the tree list; shift them past the always-tested spheres
+            for (auto &nd : nodes) if (nd.count > 0) nd.left += (int)always.size();
+        }
+    } else {
+        for (int i = 0; i < n; ++i) tree.push_back(BuildSphere{ { d->cx[i], d->cy[i], d->cz[i] }, d->r[i], i });
+    }
+    S.n_always = (int)always.size();
+    S.n_nodes = (int)nodes.size();
+
+    Carver sz{ nullptr };
+    auto layout = [&](Carver &c, std::vector<char> *host) {
+        double *cx = c.take<double>(n), *cy = c.take<double>(n), *cz = c.take<double>(n), *r2 = c.take<double>(n);
+        int32_t *sid = c.take<int32_t>(n);
+        rt3d::BvhNode *nd = c.take<rt3d::BvhNode>(nodes.size());
+        if (host) {
+            char *hb = host->data();
+            auto H = [&](auto *p) { return reinterpret_cast<decltype(p)>(hb + (reinterpret_cast<char *>(p) - c.base)); };
+            int k = 0;
+            for (const std::vector<BuildSphere> *list : { &always, &tree })
+                for (const BuildSphere &b : *list) {
+                    H(cx)[k] = b.c[0]; H(cy)[k] = b.c[1]; H(cz)[k] = b.c[2];
+                    H(r2)[k] = b.r * b.r; // radius.powi(2), rt.rs:76
+                    H(sid)[k] = b.sid;
+                    ++k;
+                }
+            if (!nodes.empty()) memcpy(H(nd), nodes.data(), sizeof(rt3d::BvhNode) * nodes.size());
+        }
+        S.cx = cx; S.cy = cy; S.cz = cz; S.r2 = r2; S.sid = sid; S.nodes = nd;
+    };
+    layout(sz, nullptr);
+    const size_t bytes = sz.off + 256;
+    rt3d_scene *sc = new (std::nothrow) rt3d_scene();
+    if (!sc) return fail(RT_E_OOM, "host allocation failed");
+    sc->ctx = ctx;
+    hipError_t e = hipMalloc(&sc->blob, bytes);
+    if (e != hipSuccess) {
+        delete sc;
+        return fail(RT_E_OOM, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e));
+    }
+    std::vector<char> host(bytes, 0);
+    Carver dc{ reinterpret_cast<char *>(sc->blob) };
+    layout(dc, &host);
+    e = hipMemcpy(sc->blob, host.data(), bytes, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        (void)hipFree(sc->blob);
+        delete sc;
+        return fail(RT_E_HIP, "scene upload: %s", hipGetErrorString(e));
+    }
+    sc->dev = S;
+    *out = sc;
+    return RT_OK;
+}
+
+int32_t rt3d_scene_destroy(rt3d_scene *scene)
+{
+    if (!scene) return RT_OK;
+    (void)hipSetDevice(scene->ctx->device);
+    (void)hipStreamSynchronize(scene->ctx->stream);
+    if (scene->blob) (void)hipFree(scene->blob);
+    delete scene;
+    return RT_OK;
+}
+
+int32_t rt3d_accumulate(rt_ctx *ctx, const rt3d_scene *scene, const rt3d_render_params *p, void *d_rgb)
+{
+    if (int32_t rc = ctx_bind(ctx)) return rc;
+    if (!scene || scene->ctx != ctx) return fail(RT_E_INVALID, "scene does not belong to this context");
+    if (!p || !d_rgb) return fail(RT_E_INVALID, "null argument");
+    if (p->spp <= 0 || p->spp > (1 << 24)) return fail(RT_E_LIMIT, "spp must be in 1..2^24 per call");
+    if (p->bounce_limit < 0 || p->bounce_limit > 4095) return fail(RT_E_LIMIT, "bounce_limit must be in 0..4095");
+    if (p->sample_offset < 0 || (int64_t)p->sample_offset + p->spp > 0x7fffffffLL) return fail(RT_E_INVALID, "sample range out of bounds");
+    rtk::Render3dArgs A{};
+    A.S = scene->dev;
+    A.spp = p->spp; A.bounce_limit = p->bounce_limit; A.sample_offset = p->sample_offset;
+    A.tiles_x = (scene->dev.width + 7) / 8;
+    A.k0 = (uint32_t)p->seed; A.k1 = (uint32_t)(p->seed >> 32);
+    A.out = (float *)d_rgb;
+    A.ray_counter = ctx->d_rays;
+    A.refill_min = refill_threshold(scene->dev.use_bvh ? 16 : scene->dev.n);
+    const int64_t tiles = (int64_t)A.tiles_x * ((scene->dev.height + 7) / 8);
+    std::pair<hipEvent_t, hipEvent_t> ev;
+    if (int32_t rc = fold_events(ctx, 256)) return rc;
+    if (int32_t rc = event_pair(ctx, &ev)) return rc;
+    HIP_TRY(hipEventRecord(ev.first, ctx->stream));
+    hipLaunchKernelGGL(rtk::render3d_kernel, dim3((unsigned)tiles), dim3(rtk::BLOCK), 0, ctx->stream, A);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(ev.second, ctx->stream));
+    ctx->pending.push_back(ev);
+    ctx->launches += 1;
+    ctx->samples += (uint64_t)scene->dev.width * (uint64_t)scene->dev.height * (uint64_t)p->spp;
+    return RT_OK;
+}
+
+int32_t rt3d_render(rt_ctx *ctx, const rt3d_scene *scene, const rt3d_render_params *p, float *out_rgb)
+{
+    if (int32_t rc = ctx_bind(ctx)) return rc;
+    if (!scene || scene->ctx != ctx) return fail(RT_E_INVALID, "scene does not belong to this context");
+    if (!out_rgb) return fail(RT_E_INVALID, "null out_rgb");
+    const size_t bytes = (size_t)scene->dev.width * scene->dev.height * 3 * sizeof(float);
+    void *ws = nullptr;
+    if (int32_t rc = ctx_workspace(ctx, bytes, &ws)) return rc;
+    HIP_TRY(hipMemsetAsync(ws, 0, bytes, ctx->stream));
+    if (int32_t rc = rt3d_accumulate(ctx, scene, p, ws)) return rc;
+    HIP_TRY(hipMemcpyAsync(out_rgb, ws, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return RT_OK;
+}
+
+int32_t rt3d_trace_batch(rt_ctx *ctx, const rt3d_scene *scene, int64_t n, const double *o, const double *d, int32_t bounce_limit,
+                         uint64_t seed, float *rgb, int32_t *first_prim, double *first_t, int32_t *bounces)
+{
+    if (int32_t rc = ctx_bind(ctx)) return rc;
+    if (!scene || scene->ctx != ctx) return fail(RT_E_INVALID, "scene does not belong to this context");
+    if (n < 0) return fail(RT_E_INVALID, "negative n");
+    if (n == 0) return RT_OK;
+    if (!o || !d || !rgb) return fail(RT_E_INVALID, "null argument");
+    if (bounce_limit < 0 || bounce_limit > 4095) return fail(RT_E_LIMIT, "bounce_limit must be in 0..4095");
+    for (int64_t i = 0; i < 3 * n; ++i)
+        if (!finite_within(o[i], MAX_COORD) || !finite_within(d[i], MAX_DIR))
+            return fail(RT_E_INVALID, "ray %lld: origin must be finite with |v| <= 2^40, direction with |v| <= 2^20", (long long)(i / 3));
+    Carver c{ nullptr };
+    c.take<double>((size_t)n * 3); c.take<double>((size_t)n * 3); c.take<double>((size_t)n);
+    c.take<float>((size_t)n * 3); c.take<int32_t>((size_t)n); c.take<int32_t>((size_t)n);
+    void *ws = nullptr;
+    if (int32_t rc = ctx_workspace(ctx, c.off + 256, &ws)) return rc;
+    Carver w{ (char *)ws };
+    double *d_o = w.take<double>((size_t)n * 3), *d_d = w.take<double>((size_t)n * 3), *d_ft = w.take<double>((size_t)n);
+    float *d_rgb = w.take<float>((size_t)n * 3);
+    int32_t *d_fp = w.take<int32_t>((size_t)n), *d_nb = w.take<int32_t>((size_t)n);
+    HIP_TRY(hipMemcpyAsync(d_o, o, sizeof(double) * 3 * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(d_d, d, sizeof(double) * 3 * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    std::pair<hipEvent_t, hipEvent_t> ev;
+    if (int32_t rc = fold_events(ctx, 256)) return rc;
+    if (int32_t rc = event_pair(ctx, &ev)) return rc;
+    HIP_TRY(hipEventRecord(ev.first, ctx->stream));
+    const unsigned blocks = (unsigned)((n + rtk::BLOCK - 1) / rtk::BLOCK);
+    hipLaunchKernelGGL(rtk::trace_batch3d_kernel, dim3(blocks), dim3(rtk::BLOCK), 0, ctx->stream, scene->dev, n, d_o, d_d,
+                       bounce_limit, (uint32_t)seed, (uint32_t)(seed >> 32), d_rgb, d_fp, d_ft, d_nb, ctx->d_rays);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(ev.second, ctx->stream));
+    ctx->pending.push_back(ev);
+    ctx->launches += 1;
+    ctx->samples += (uint64_t)n;
+    HIP_TRY(hipMemcpyAsync(rgb, d_rgb, sizeof(float) * 3 * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    if (first_prim) HIP_TRY(hipMemcpyAsync(first_prim, d_fp, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    if (first_t) HIP_TRY(hipMemcpyAsync(first_t, d_ft, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    if (bounces) HIP_TRY(hipMemcpyAsync(bounces, d_nb, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return RT_OK;
+}
+
+int32_t rt_tonemap_reinhard(rt_ctx *ctx, const float *rgb, int64_t n_pixels, float param, uint8_t alpha, uint8_t *out_rgba8)
+{
+    if (int32_t rc = ctx_bind(ctx)) return rc;
+    if (n_pixels < 0) return fail(RT_E_INVALID, "negative n_pixels");
+    if (n_pixels == 0) return RT_OK;
+    if (!rgb || !out_rgba8) return fail(RT_E_INVALID, "null argument");
+    Carver c{ nullptr };
+    c.take<float>((size_t)n_pixels * 3); c.take<uint32_t>((size_t)n_pixels);
+    void *ws = nullptr;
+    if (int32_t rc = ctx_workspace(ctx, c.off + 256, &ws)) return rc;
+    Carver w{ (char *)ws };
+    float *d_rgb = w.take<float>((size_t)n_pixels * 3);
+    uint32_t *d_out = w.take<uint32_t>((size_t)n_pixels);
+    HIP_TRY(hipMemcpyAsync(d_rgb, rgb, sizeof(float) * 3 * (size_t)n_pixels, hipMemcpyHostToDevice, ctx->stream));
+    const unsigned blocks = (unsigned)((n_pixels + 255) / 256);
+    hipLaunchKernelGGL(rtk::reinhard_kernel, dim3(blocks), dim3(256), 0, ctx->stream, (const float *)d_rgb, n_pixels, param,
+                       (uint32_t)alpha, d_out);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out_rgba8, d_out, sizeof(uint32_t) * (size_t)n_pixels, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return RT_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,131 @@
+// Device-side arithmetic shared by the 2d and 3d trace kernels (gfx950).
+//
+// Everything here is built from IEEE + - * / sqrt only and must be compiled
+// with -ffp-contract=off: the reference (Rust) never fuses a*b+c, and hit
+// primitive ids / bounce counts are only reproducible bit for bit when every
+// f64 operation rounds the same way on the host restatement and on the device.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define RT_DEV __device__ __forceinline__
+
+namespace rtd {
+
+constexpr int NBINS = 95;              // SPECTRUM_SAMPLES, 2d/src/spectrum.rs:106
+constexpr double EPS64 = 0x1.0p-52;    // f64::EPSILON
+
+// ---------------------------------------------------------------------------
+// Philox4x32-10 counter-based generator (Salmon et al. 2011).  Stands in for
+// rand::random (2d/src/librt2d_reverse.rs:89, rt_common.rs:370,379-380,
+// spectrum.rs:186, 3d/src/rt.rs:41,181): the key is the caller's seed, the
+// counter names (pixel | ray, sample, lambda-sample, bounce/attempt), so a
+// number never depends on which lane or launch asks for it.
+struct U4 { uint32_t x, y, z, w; };
+
+RT_DEV U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1)
+{
+#pragma unroll
+    for (int round = 0; round < 10; ++round) {
+        const uint32_t lo0 = 0xD2511F53u * c0, hi0 = __umulhi(0xD2511F53u, c0);
+        const uint32_t lo1 = 0xCD9E8D57u * c2, hi1 = __umulhi(0xCD9E8D57u, c2);
+        const uint32_t n0 = hi1 ^ c1 ^ k0;
+        const uint32_t n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    return U4{ c0, c1, c2, c3 };
+}
+
+// 53-bit uniform in [0,1): ((hi:lo) >> 11) * 2^-53, as rand's f64 sampling does.
+RT_DEV double u01(uint32_t lo, uint32_t hi)
+{
+    const uint64_t v = ((uint64_t)hi << 32) | lo;
+    return (double)(v >> 11) * 0x1.0p-53;
+}
+
+// ---------------------------------------------------------------------------
+// (sin, cos)(2*pi*u), u in [0,1): quadrant reduction + degree 15/16 Taylor
+// polynomials on [-pi/4, pi/4], Horner form, no fused operations.  Fixed
+// evaluation order so host and device agree to the last bit (libm / ocml
+// sin/cos do not).  Used where the reference calls DVec2::from_angle
+// (2d/src/rt_common.rs:371).
+RT_DEV void sincos2pi(double u, double &s, double &c)
+{
+    const double x = u * 4.0;
+    const int q = (int)(x + 0.5);
+    const double r = x - (double)q;
+    const double th = r * 0x1.921fb54442d18p+0;
+    const double z = th * th;
+    double ps = -0x1.ae7f3e733b81fp-41;
+    ps = ps * z + 0x1.6124613a86d09p-33;
+    ps = ps * z + -0x1.ae64567f544e4p-26;
+    ps = ps * z + 0x1.71de3a556c734p-19;
+    ps = ps * z + -0x1.a01a01a01a01ap-13;
+    ps = ps * z + 0x1.1111111111111p-7;
+    ps = ps * z + -0x1.5555555555555p-3;
+    const double sn = th + (th * z) * ps;
+    double pc = 0x1.ae7f3e733b81fp-45;
+    pc = pc * z + -0x1.93974a8c07c9dp-37;
+    pc = pc * z + 0x1.1eed8eff8d898p-29;
+    pc = pc * z + -0x1.27e4fb7789f5cp-22;
+    pc = pc * z + 0x1.a01a01a01a01ap-16;
+    pc = pc * z + -0x1.6c16c16c16c17p-10;
+    pc = pc * z + 0x1.5555555555555p-5;
+    const double cs = (1.0 - 0.5 * z) + (z * z) * pc;
+    const int k = q & 3;
+    s = (k == 0) ? sn : (k == 1) ? cs : (k == 2) ? -sn : -cs;
+    c = (k == 0) ? cs : (k == 1) ? -sn : (k == 2) ? -cs : sn;
+}
+
+// e^x in f32 with a fixed evaluation order (f32::exp at
+// 2d/src/librt2d_reverse.rs:159 is platform libm): n = round(x log2 e),
+// two-constant ln2 reduction, degree-7 polynomial, scaling by 2^n.
+RT_DEV float expf_fixed(float x)
+{
+    if (x != x) return x;
+    if (x > 88.72283f) return __builtin_inff();
+    if (x < -103.97f) return 0.0f;
+    const float fn = x * 0x1.715476p+0f;
+    int n = (int)(fn + (fn < 0.0f ? -0.5f : 0.5f));
+    const float nf = (float)n;
+    float r = x - nf * 0x1.63p-1f;
+    r = r - nf * -0x1.bd0106p-13f;
+    float p = 0x1.a01a02p-13f;
+    p = p * r + 0x1.6c16c2p-10f;
+    p = p * r + 0x1.111112p-7f;
+    p = p * r + 0x1.555556p-5f;
+    p = p * r + 0x1.555556p-3f;
+    p = p * r + 0.5f;
+    float e = 1.0f + (r + (r * r) * p);
+    if (n < -125) { e = e * 0x1.0p-64f; n += 64; }
+    if (n > 127) { e = e * 2.0f; n -= 1; }
+    return e * __uint_as_float((uint32_t)(n + 127) << 23);
+}
+
+// Key whose signed integer order is f64::total_cmp's order (the comparison
+// min_by / sort_by use at librt2d_reverse.rs:139, rt_common.rs:302,
+// 3d/src/rt.rs:224): -0.0 sorts before +0.0.
+RT_DEV int64_t total_key(double t)
+{
+    int64_t k = __double_as_longlong(t);
+    k ^= (int64_t)((uint64_t)(k >> 63) >> 1);
+    return k;
+}
+
+RT_DEV int hi32(double x) { return __double2hiint(x); }
+
+// 1/len with len = sqrt(x.x + y.y): glam's normalize multiplies by the reciprocal.
+RT_DEV double rlen2(double x, double y) { return 1.0 / __builtin_sqrt(x * x + y * y); }
+RT_DEV double rlen3(double x, double y, double z) { return 1.0 / __builtin_sqrt((x * x + y * y) + z * z); }
+
+// wave64 helpers
+RT_DEV int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+RT_DEV int rank_in_mask(uint64_t mask)
+{
+    return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+} // namespace rtd

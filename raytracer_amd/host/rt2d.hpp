@@ -1,0 +1,428 @@
+// Host-side mirror of the 2d crate's scene / renderer interface, in C++ because
+// no Rust toolchain exists where this is built.  Same names, argument meaning
+// and error behaviour as the reference so that callers (and the parity tests)
+// read like the reference's own code; the per-ray work itself is done by the
+// HIP library behind include/rt_abi.h.
+//
+// Mirrors (paths relative to the reference root):
+//   2d/src/spectrum.rs      Spectrum, SpectrumColor
+//   2d/src/rt_common.rs     Circle, Segment, Strip, Bezier, Shape, Ior, Material, Object, Camera, World
+//   2d/src/worlds.rs        the scene builders
+//   2d/src/img.rs           PixelData, RawImage, Blending, ToneMappingMethod
+//   2d/src/librt2d_reverse.rs  ReverseRenderParams, ReverseRenderer
+#pragma once
+
+#include <array>
+#include <cmath>
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <variant>
+#include <vector>
+
+#include "../../include/rt_abi.h"
+
+namespace rt2d_host {
+
+constexpr double PI = 3.14159265358979323846;
+constexpr int SPECTRUM_SAMPLES = RT_NBINS;
+
+// glam::DVec2 subset (formulas as published by glam 0.33)
+struct DVec2 {
+    double x = 0.0, y = 0.0;
+    DVec2() = default;
+    DVec2(double x_, double y_) : x(x_), y(y_) {}
+    static DVec2 from_angle(double a) { return DVec2(std::cos(a), std::sin(a)); }
+    DVec2 operator+(DVec2 o) const { return DVec2(x + o.x, y + o.y); }
+    DVec2 operator-(DVec2 o) const { return DVec2(x - o.x, y - o.y); }
+    DVec2 operator*(double s) const { return DVec2(x * s, y * s); }
+    DVec2 operator/(double s) const { return DVec2(x / s, y / s); }
+    double dot(DVec2 o) const { return x * o.x + y * o.y; }
+    double length() const { return std::sqrt(dot(*this)); }
+    DVec2 perp() const { return DVec2(-y, x); }
+    DVec2 normalize() const { const double r = 1.0 / length(); return DVec2(x * r, y * r); }
+    DVec2 lerp(DVec2 rhs, double s) const { return *this * (1.0 - s) + rhs * s; }
+};
+
+// ---- spectrum.rs ----------------------------------------------------------
+enum class SpectrumColor { Black, Violet, Blue, Cyan, Green, Yellow, Orange, Red, White };
+
+inline std::vector<SpectrumColor> iter_colors()
+{
+    return { SpectrumColor::Black, SpectrumColor::Violet, SpectrumColor::Blue,   SpectrumColor::Cyan, SpectrumColor::Green,
+             SpectrumColor::Yellow, SpectrumColor::Orange, SpectrumColor::Red, SpectrumColor::White };
+}
+
+struct Spectrum {
+    std::array<float, SPECTRUM_SAMPLES> data{}; // 360 nm .. 830 nm, step 5 nm (spectrum.rs:106-115)
+
+    // spectrum.rs:218-239
+    static Spectrum emission_from_color(SpectrumColor color)
+    {
+        int lo = 0, hi = -1;
+        switch (color) {
+        case SpectrumColor::Black: return Spectrum();
+        case SpectrumColor::Violet: lo = 380; hi = 450; break;
+        case SpectrumColor::Blue: lo = 450; hi = 485; break;
+        case SpectrumColor::Cyan: lo = 485; hi = 500; break;
+        case SpectrumColor::Green: lo = 500; hi = 565; break;
+        case SpectrumColor::Yellow: lo = 565; hi = 590; break;
+        case SpectrumColor::Orange: lo = 590; hi = 625; break;
+        case SpectrumColor::Red: lo = 625; hi = 750; break;
+        case SpectrumColor::White: lo = 360; hi = 830; break;
+        }
+        Spectrum s;
+        for (int i = 0; i < SPECTRUM_SAMPLES; ++i) {
+            const int l = 360 + 5 * i;
+            if (l >= lo && l <= hi) s.data[(size_t)i] = 1.0f;
+        }
+        return s;
+    }
+    // spectrum.rs:214-216
+    static Spectrum absorption_from_color(SpectrumColor color)
+    {
+        return emission_from_color(SpectrumColor::White) - emission_from_color(color);
+    }
+    Spectrum operator-(const Spectrum &o) const
+    {
+        Spectrum r;
+        for (size_t i = 0; i < data.size(); ++i) r.data[i] = data[i] - o.data[i];
+        return r;
+    }
+    Spectrum operator+(const Spectrum &o) const
+    {
+        Spectrum r;
+        for (size_t i = 0; i < data.size(); ++i) r.data[i] = data[i] + o.data[i];
+        return r;
+    }
+    Spectrum operator*(float k) const
+    {
+        Spectrum r;
+        for (size_t i = 0; i < data.size(); ++i) r.data[i] = data[i] * k;
+        return r;
+    }
+    bool operator==(const Spectrum &o) const { return data == o.data; }
+};
+
+// ---- rt_common.rs ---------------------------------------------------------
+struct Circle { DVec2 center; double r = 0.0; };
+
+struct Segment {
+    DVec2 a, b, n;
+    Segment() = default;
+    // Segment::new, rt_common.rs:209-212
+    Segment(DVec2 a_, DVec2 b_) : a(a_), b(b_), n((b_ - a_).perp().normalize()) {}
+    Segment flip() const { return Segment(b, a); }
+};
+
+struct Strip { std::vector<Segment> strip; };
+
+// rt_common.rs:123-193
+struct Bezier {
+    std::vector<DVec2> control_points;
+    DVec2 at(double t) const
+    {
+        std::vector<DVec2> prev = control_points;
+        for (size_t k = 1; k < control_points.size(); ++k) {
+            std::vector<DVec2> next;
+            for (size_t i = 0; i + 1 < prev.size(); ++i) next.push_back(prev[i].lerp(prev[i + 1], t));
+            prev.swap(next);
+        }
+        if (prev.size() != 1) throw std::logic_error("Bezier::at: empty control polygon");
+        return prev[0];
+    }
+    // yields resolution-1 segments over t in [0, (resolution-1)/resolution]
+    std::vector<Segment> as_segments(size_t resolution) const
+    {
+        std::vector<Segment> out;
+        for (size_t t = 0; t + 1 < resolution; ++t) {
+            const double t0 = (double)t / (double)resolution, t1 = (double)(t + 1) / (double)resolution;
+            out.emplace_back(at(t0), at(t1));
+        }
+        return out;
+    }
+};
+
+using Shape = std::variant<Circle, Segment, Strip>;
+
+struct Ior {
+    enum Kind { Simple = 0, Cauchy = 1 } kind = Simple;
+    double a = 1.0, b = 0.0;
+    static Ior simple(double v) { return Ior{ Simple, v, 0.0 }; }
+    static Ior cauchy(double a_, double b_) { return Ior{ Cauchy, a_, b_ }; }
+    // rt_common.rs:442-450
+    double ior(double lambda) const
+    {
+        const double l = lambda / 1000.0;
+        return kind == Simple ? a : a + b / (l * l);
+    }
+};
+
+struct Material {
+    enum Kind { Emissive = 0, DirectionalEmissive = 1, Diffuse = 2, Reflective = 3, Dielectric = 4 } kind = Reflective;
+    Spectrum spectrum; // emission | absorption (Diffuse albedo, Dielectric Beer-Lambert coefficient)
+    double angle = 0.0, d = 0.0;
+    Ior ior_;
+
+    static Material emissive(const Spectrum &s) { Material m; m.kind = Emissive; m.spectrum = s; return m; }
+    // rt_common.rs:459-466: emission is pre-multiplied by d
+    static Material directional_emissive_at(double d, double angle, const Spectrum &emission)
+    {
+        Material m; m.kind = DirectionalEmissive; m.spectrum = emission * (float)d; m.d = d; m.angle = angle; return m;
+    }
+    static Material diffuse(const Spectrum &absorption) { Material m; m.kind = Diffuse; m.spectrum = absorption; return m; }
+    static Material reflective() { Material m; m.kind = Reflective; return m; }
+    static Material dielectric(Ior ior, const Spectrum &absorption)
+    {
+        Material m; m.kind = Dielectric; m.ior_ = ior; m.spectrum = absorption; return m;
+    }
+    static Material dieletric(double ior, const Spectrum &absorption) { return dielectric(Ior::simple(ior), absorption); }
+};
+
+struct Object {
+    Shape shape;
+    Material mat;
+    static Object segment(DVec2 a, DVec2 b, const Material &m) { return Object{ Segment(a, b), m }; }
+    static Object bezier(const std::vector<DVec2> &pts, size_t resolution, const Material &m)
+    {
+        return Object{ Strip{ Bezier{ pts }.as_segments(resolution) }, m };
+    }
+    // rt_common.rs:512-526: closed polygon
+    static Object from_points(const std::vector<DVec2> &pts, const Material &m)
+    {
+        if (pts.size() < 2) throw std::invalid_argument("from_points needs at least 2 points");
+        Strip s;
+        for (size_t i = 0; i + 1 < pts.size(); ++i) s.strip.emplace_back(pts[i], pts[i + 1]);
+        s.strip.emplace_back(pts.back(), pts.front());
+        return Object{ s, m };
+    }
+};
+
+struct Camera { DVec2 center, size; };
+
+struct World {
+    Camera camera;
+    std::vector<Object> objects;
+};
+
+// ---- flat SoA view handed to the C ABI -------------------------------------
+struct FlatScene {
+    std::vector<double> ccx, ccy, cr, sax, say, sbx, sby, snx, sny;
+    std::vector<int32_t> cobj, cpid, sobj, spid;
+    std::vector<rt2d_material> materials;
+    std::vector<float> spectra;
+
+    rt2d_scene_desc desc() const
+    {
+        rt2d_scene_desc d{};
+        d.n_circles = (int32_t)ccx.size(); d.n_segments = (int32_t)sax.size();
+        d.n_objects = (int32_t)materials.size(); d.n_spectra = (int32_t)(spectra.size() / RT_NBINS);
+        d.circle_cx = ccx.data(); d.circle_cy = ccy.data(); d.circle_r = cr.data();
+        d.circle_obj = cobj.data(); d.circle_pid = cpid.data();
+        d.seg_ax = sax.data(); d.seg_ay = say.data(); d.seg_bx = sbx.data(); d.seg_by = sby.data();
+        d.seg_nx = snx.data(); d.seg_ny = sny.data(); d.seg_obj = sobj.data(); d.seg_pid = spid.data();
+        d.materials = materials.data(); d.spectra = spectra.data();
+        return d;
+    }
+};
+
+// Object list -> SoA in scan order (object order, then segment order inside a Strip).
+inline FlatScene flatten(const World &w)
+{
+    FlatScene f;
+    int32_t pid = 0;
+    for (size_t o = 0; o < w.objects.size(); ++o) {
+        const Object &ob = w.objects[o];
+        auto push_seg = [&](const Segment &s) {
+            f.sax.push_back(s.a.x); f.say.push_back(s.a.y); f.sbx.push_back(s.b.x); f.sby.push_back(s.b.y);
+            f.snx.push_back(s.n.x); f.sny.push_back(s.n.y);
+            f.sobj.push_back((int32_t)o); f.spid.push_back(pid++);
+        };
+        if (const Circle *c = std::get_if<Circle>(&ob.shape)) {
+            f.ccx.push_back(c->center.x); f.ccy.push_back(c->center.y); f.cr.push_back(c->r);
+            f.cobj.push_back((int32_t)o); f.cpid.push_back(pid++);
+        } else if (const Segment *s = std::get_if<Segment>(&ob.shape)) {
+            push_seg(*s);
+        } else {
+            for (const Segment &s : std::get<Strip>(ob.shape).strip) push_seg(s);
+        }
+        rt2d_material m{};
+        m.kind = (int32_t)ob.mat.kind;
+        m.ior_kind = (int32_t)ob.mat.ior_.kind;
+        m.ior_a = ob.mat.ior_.a; m.ior_b = ob.mat.ior_.b;
+        m.angle = ob.mat.angle; m.d = ob.mat.d;
+        m.spectrum = (int32_t)(f.spectra.size() / RT_NBINS);
+        f.spectra.insert(f.spectra.end(), ob.mat.spectrum.data.begin(), ob.mat.spectrum.data.end());
+        f.materials.push_back(m);
+    }
+    return f;
+}
+
+// ---- img.rs -----------------------------------------------------------------
+struct Vec3 { float x = 0.0f, y = 0.0f, z = 0.0f; };
+struct PixelData { float weight = 1.0f; Vec3 value; }; // img.rs:20-33
+enum class Blending { Add, Blend, Replace };
+struct ToneMappingMethod { float param = 1.0f; }; // Reinhard { param }
+
+struct RawImage {
+    int32_t width = 0, height = 0;
+    std::vector<PixelData> data;
+    RawImage(int32_t w, int32_t h) : width(w), height(h), data((size_t)w * (size_t)h) {}
+    // img.rs:93-99; out of range -> false (the reference's Err(()))
+    bool pixel_to_idx(int x, int y, size_t &idx) const
+    {
+        if (x < 0 || x >= width || y < 0 || y >= height) return false;
+        idx = (size_t)(width * y + x);
+        return true;
+    }
+    // img.rs:117-142
+    bool draw_pixel(int x, int y, const PixelData &p, Blending b)
+    {
+        size_t i;
+        if (!pixel_to_idx(x, y, i)) return false;
+        PixelData &d = data[i];
+        switch (b) {
+        case Blending::Add:
+            d.value.x += p.value.x; d.value.y += p.value.y; d.value.z += p.value.z; d.weight += p.weight; break;
+        case Blending::Blend: {
+            const float w = d.weight + p.weight;
+            d.value.x = (d.value.x + p.value.x) / w; d.value.y = (d.value.y + p.value.y) / w; d.value.z = (d.value.z + p.value.z) / w;
+            d.weight = w;
+            break;
+        }
+        case Blending::Replace: d = p; break;
+        }
+        return true;
+    }
+};
+
+// ---- librt2d_reverse.rs -----------------------------------------------------
+struct ReverseRenderParams {
+    int32_t width = 800, height = 600;
+    size_t spp = 1;
+    size_t recursion_limit = 10;
+    size_t lambda_samples = 1;
+    // not in the reference: its generator is unseeded and its image is 800x600
+    uint64_t seed = 0;
+    int32_t sample_offset = 0;
+    double px_to_world = 1.0;
+};
+
+struct Ray2d { DVec2 origin, dir; };
+
+class RtError : public std::runtime_error {
+public:
+    using std::runtime_error::runtime_error;
+};
+
+// GPU context + uploaded scene with the reference's method names.  A failed
+// call throws RtError (the reference unwraps / panics on its few failure paths).
+class ReverseRenderer {
+public:
+    ReverseRenderParams render_params;
+
+    ReverseRenderer(const ReverseRenderParams &p, int device = 0) : render_params(p)
+    {
+        check(rt_ctx_create(device, &ctx_));
+    }
+    ~ReverseRenderer()
+    {
+        if (scene_) rt2d_scene_destroy(scene_);
+        if (ctx_) rt_ctx_destroy(ctx_);
+    }
+    ReverseRenderer(const ReverseRenderer &) = delete;
+    ReverseRenderer &operator=(const ReverseRenderer &) = delete;
+
+    rt_ctx *context() const { return ctx_; }
+
+    // librt2d_reverse.rs:282-302
+    RawImage global_render(const World &world, const ReverseRenderParams &p)
+    {
+        bind(world);
+        const rt2d_render_params rp = abi_params(p);
+        const size_t n = (size_t)p.width * (size_t)p.height;
+        std::vector<float> rgb(n * 3), weight(n);
+        check(rt2d_render(ctx_, scene_, &rp, rgb.data(), weight.data(), nullptr));
+        RawImage img(p.width, p.height);
+        for (size_t i = 0; i < n; ++i) {
+            img.data[i].weight = weight[i];
+            img.data[i].value = Vec3{ rgb[3 * i], rgb[3 * i + 1], rgb[3 * i + 2] };
+        }
+        return img;
+    }
+
+    // librt2d_reverse.rs:264-279: (j, (spectrum, spp)) for every row j of column i
+    std::vector<std::pair<int32_t, std::pair<Spectrum, size_t>>> render_column(const World &world, const ReverseRenderParams &p,
+                                                                              int32_t i)
+    {
+        bind(world);
+        std::vector<int32_t> px((size_t)p.height, i), py((size_t)p.height);
+        for (int32_t j = 0; j < p.height; ++j) py[(size_t)j] = j;
+        std::vector<Spectrum> sp = compute_pixels(p, px, py);
+        std::vector<std::pair<int32_t, std::pair<Spectrum, size_t>>> out;
+        for (int32_t j = 0; j < p.height; ++j) out.push_back({ j, { sp[(size_t)j], p.spp } });
+        return out;
+    }
+
+    // librt2d_reverse.rs:80-110
+    Spectrum compute_pixel(const World &world, int32_t px, int32_t py, const ReverseRenderParams &p)
+    {
+        bind(world);
+        return compute_pixels(p, { px }, { py })[0];
+    }
+
+    // librt2d_reverse.rs:112-262.  `ray_index` names the ray's random stream.
+    float trace_ray(const World &world, const Ray2d &ray, size_t lambda_idx, double /*lambda*/, size_t depth)
+    {
+        bind(world);
+        const int32_t li = (int32_t)lambda_idx;
+        float out = 0.0f;
+        check(rt2d_trace_batch(ctx_, scene_, 1, &ray.origin.x, &ray.origin.y, &ray.dir.x, &ray.dir.y, &li, (int32_t)depth,
+                               render_params.seed, &out, nullptr, nullptr, nullptr));
+        return out;
+    }
+
+    std::vector<Spectrum> compute_pixels(const ReverseRenderParams &p, const std::vector<int32_t> &px, const std::vector<int32_t> &py)
+    {
+        if (!scene_) throw RtError("no world bound");
+        const rt2d_render_params rp = abi_params(p);
+        std::vector<float> flat(px.size() * RT_NBINS);
+        check(rt2d_compute_pixels(ctx_, scene_, &rp, (int64_t)px.size(), px.data(), py.data(), flat.data()));
+        std::vector<Spectrum> out(px.size());
+        for (size_t k = 0; k < px.size(); ++k)
+            for (int b = 0; b < RT_NBINS; ++b) out[k].data[(size_t)b] = flat[k * RT_NBINS + (size_t)b];
+        return out;
+    }
+
+    // Upload `world` unless it is the one already resident (compared by address and object count).
+    void bind(const World &world)
+    {
+        if (scene_ && bound_ == &world && bound_objects_ == world.objects.size()) return;
+        if (scene_) { rt2d_scene_destroy(scene_); scene_ = nullptr; }
+        const FlatScene f = flatten(world);
+        const rt2d_scene_desc d = f.desc();
+        check(rt2d_scene_create(ctx_, &d, &scene_));
+        bound_ = &world;
+        bound_objects_ = world.objects.size();
+    }
+
+private:
+    static rt2d_render_params abi_params(const ReverseRenderParams &p)
+    {
+        rt2d_render_params r{};
+        r.width = p.width; r.height = p.height; r.spp = (int32_t)p.spp; r.lambda_samples = (int32_t)p.lambda_samples;
+        r.recursion_limit = (int32_t)p.recursion_limit; r.sample_offset = p.sample_offset; r.seed = p.seed;
+        r.px_to_world = p.px_to_world;
+        return r;
+    }
+    static void check(int32_t rc)
+    {
+        if (rc != RT_OK) throw RtError(std::string("rt_abi call failed (") + std::to_string(rc) + "): " + rt_last_error());
+    }
+    rt_ctx *ctx_ = nullptr;
+    rt2d_scene *scene_ = nullptr;
+    const World *bound_ = nullptr;
+    size_t bound_objects_ = 0;
+};
+
+} // namespace rt2d_host
