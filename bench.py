@@ -1,0 +1,172 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Mrays/s of the per-ray hot path on N MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+Workload at N = 1 (BASELINE.json configs[1]): the 2d stress-test scene
+(`complex_world`, 200 circles, Philox seed 1) at 1920x1080, lambda_samples 2,
+recursion limit 10, f64 geometry / f32 radiance.  One step = one pass of
+`--spp` (64) samples per pixel over the whole image (rt2d_accumulate), the
+spectral radiance buffer staying resident in HBM.  The timed job is K steps,
+then — for N > 1 — one RCCL all-reduce of the per-GPU spectral buffers, then the
+resolve to sRGB.  With N GPUs every rank renders its own sample range of every
+pixel (weak scaling: per-GPU work is fixed, total samples grow with N).
+
+1 ray = one trace_ray invocation with depth > 0 (one nearest-hit query);
+1 sample = one top-level trace_ray call.  Ray counts are data dependent and are
+read back from the device counter after the timed region.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+F64_VECTOR_PEAK_TFLOPS = 78.6   # MI355X public spec: 256 CU x 4 SIMD x 16 f64 lanes x 2 (FMA) x 2.4 GHz
+HBM_PEAK_GBS = 8000.0
+FLOP_PER_TEST_2D = 15.0         # ray-circle / ray-segment test
+FLOP_PER_SHADE = 60.0
+
+
+def cpu_baseline(world, p_full, threads, spp_sample):
+    """The CPU restatement of the reference's render path (serial over columns, thread pool over
+    rows) timed on the host cores on a bounded sample: the same image at `spp_sample` samples."""
+    from tests.oracle_ffi import Oracle
+    from raytracer_amd.api import params2d
+    so = os.path.join(ROOT, "oracle", "build", "librt_oracle.so")
+    oracle = Oracle(so)
+    p = params2d(p_full.width, p_full.height, spp_sample, p_full.lambda_samples, p_full.recursion_limit,
+                 seed=p_full.seed, px_to_world=p_full.px_to_world)
+    t0 = time.perf_counter()
+    _, _, _, rays = oracle.render2d(world, p, threads=threads, want_spectrum=False)
+    dt = time.perf_counter() - t0
+    return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
+            "sample": f"same scene and image at spp {spp_sample} ({rays} rays in {dt:.1f} s), "
+                      f"C restatement of the reference CPU path, {threads} threads",
+            "samples_per_s": p.width * p.height * spp_sample * p.lambda_samples / dt}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--scene", default="complex_world")
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--spp", type=int, default=64, help="samples per pixel per step")
+    ap.add_argument("--lambda-samples", type=int, default=2)
+    ap.add_argument("--depth", type=int, default=10)
+    ap.add_argument("--cpu-spp", type=int, default=4, help="spp of the bounded CPU-baseline sample (0 = skip)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world_size = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world_size != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world_size}: launch with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the hot path has no CPU implementation")
+    torch.cuda.set_device(local_rank)
+    if world_size > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import raytracer_amd as rt
+    from raytracer_amd.api import params2d
+
+    world = rt.World2D(args.scene, seed=1)
+    stream = torch.cuda.current_stream()
+    ctx = rt.Context(local_rank, stream=stream.cuda_stream)
+    scene = rt.Scene2D(ctx, world)
+    W, H = args.width, args.height
+    spectrum = torch.zeros(W * H * rt.NBINS, dtype=torch.float32, device="cuda")
+    rgb = torch.empty(W * H * 3, dtype=torch.float32, device="cuda")
+
+    def step(i):
+        # global sample index: step-major, rank-minor, so no two ranks or steps share a sample
+        off = (i * world_size + rank) * args.spp
+        scene.accumulate(params2d(W, H, args.spp, args.lambda_samples, args.depth, seed=0, sample_offset=off),
+                         spectrum.data_ptr())
+
+    def finish(n_steps):
+        if world_size > 1:
+            dist.all_reduce(spectrum, op=dist.ReduceOp.SUM)
+        scene.resolve(spectrum.data_ptr(), W, H, n_steps * args.spp * world_size, d_rgb_ptr=rgb.data_ptr(), to_host=False)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world_size > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    if args.warmup:
+        finish(args.warmup)
+    barrier()
+    spectrum.zero_()
+    ctx.reset_stats()
+
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    finish(args.steps)
+    barrier()
+    dt = time.perf_counter() - t0
+
+    st = ctx.stats()
+    t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    counts = torch.tensor([st["rays"], st["samples"]], dtype=torch.float64, device="cuda")
+    if world_size > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(counts, op=dist.ReduceOp.SUM)
+    dt = float(t.item())
+    total_rays, total_samples = float(counts[0].item()), float(counts[1].item())
+
+    if rank == 0:
+        P = world.n_prims
+        kernel_ms = st["kernel_ms"] / max(1, st["launches"])           # this rank's average launch duration
+        rays_per_launch = st["rays"] / max(1, st["launches"])
+        flop_per_launch = rays_per_launch * (FLOP_PER_TEST_2D * P + FLOP_PER_SHADE)
+        achieved = flop_per_launch / (kernel_ms * 1e-3) / 1e12
+        # algorithmic HBM bytes of one launch: read-modify-write of the spectral buffer (380 B per pixel each way)
+        hbm_bytes = 2.0 * W * H * rt.NBINS * 4
+        out = {
+            "metric": "Mrays/s", "value": total_rays / dt / 1e6, "unit": "Mrays/s",
+            "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"2d stress_test ({args.scene}, {P} primitives, seed 1) {W}x{H}, "
+                                   f"{args.spp} spp/step, lambda_samples {args.lambda_samples}, depth {args.depth}; "
+                                   f"job = {args.steps} steps + spectral all-reduce + resolve",
+                       "parallelism": f"sample-batch x{world_size}", "mode": "f64 geometry / f32 radiance (parity mode)"},
+            "samples_per_s": total_samples / dt,
+            "rays_per_sample": total_rays / max(1.0, total_samples),
+            "roofline": {"bound": "valu", "achieved": achieved, "peak": F64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / F64_VECTOR_PEAK_TFLOPS, "traffic": None,
+                         "kernel": "render2d_kernel", "kernel_ms": kernel_ms,
+                         "flop_model": f"rays x (15 x {P} + 60), FMA-rate f64 vector peak; the kernel may not fuse "
+                                       "(reference arithmetic is unfused), so 0.5 is its ceiling",
+                         "hbm": {"achieved": hbm_bytes / (kernel_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": hbm_bytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}},
+        }
+        if args.cpu_spp > 0 and world_size == 1:
+            threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
+            p_full = params2d(W, H, args.spp, args.lambda_samples, args.depth, seed=0)
+            out["cpu_baseline"] = cpu_baseline(world, p_full, threads, args.cpu_spp)
+        print(json.dumps(out), flush=True)
+
+    if world_size > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -152,7 +152,7 @@ def params2d(width, height, spp, lambda_samples, recursion_limit, seed=0, sample
     p = RenderParams2D()
     p.width, p.height, p.spp, p.lambda_samples = int(width), int(height), int(spp), int(lambda_samples)
     p.recursion_limit, p.sample_offset, p.seed = int(recursion_limit), int(sample_offset), int(seed)
-    p.px_to_world = float(800.0 / width if px_to_world is None else px_to_world)
+    p.px_to_world = float((800.0 / width if width > 0 else 1.0) if px_to_world is None else px_to_world)
     return p
 
 
