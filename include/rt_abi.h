@@ -134,8 +134,11 @@ const char *rt_last_error(void);
 int32_t rt_device_count(int32_t *count);
 int32_t rt_ctx_create(int32_t device_id, rt_ctx **out);
 int32_t rt_ctx_destroy(rt_ctx *ctx);
-/* Work is enqueued on `hip_stream` (a hipStream_t; NULL = the context's own stream). */
+/* A new context enqueues its work on a non-blocking stream of its own.
+ * rt_ctx_set_stream switches it to the caller's `hip_stream` (a hipStream_t; NULL is
+ * HIP's null stream, as everywhere in HIP); rt_ctx_use_own_stream switches back. */
 int32_t rt_ctx_set_stream(rt_ctx *ctx, void *hip_stream);
+int32_t rt_ctx_use_own_stream(rt_ctx *ctx);
 int32_t rt_ctx_synchronize(rt_ctx *ctx);
 /* Both synchronize the stream first. */
 int32_t rt_ctx_get_stats(rt_ctx *ctx, rt_stats *out);

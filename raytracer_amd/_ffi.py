@@ -63,6 +63,7 @@ ABI = {
     "rt_ctx_create": (C.c_int32, [C.c_int32, C.POINTER(C.c_void_p)]),
     "rt_ctx_destroy": (C.c_int32, [C.c_void_p]),
     "rt_ctx_set_stream": (C.c_int32, [C.c_void_p, C.c_void_p]),
+    "rt_ctx_use_own_stream": (C.c_int32, [C.c_void_p]),
     "rt_ctx_synchronize": (C.c_int32, [C.c_void_p]),
     "rt_ctx_get_stats": (C.c_int32, [C.c_void_p, C.POINTER(Stats)]),
     "rt_ctx_reset_stats": (C.c_int32, [C.c_void_p]),
@@ -114,7 +115,8 @@ _host = None
 def lib():
     global _lib
     if _lib is None:
-        _lib = _load("librt_amd.so", ABI)
+        # RT_AMD_LIBNAME selects a diagnostic build of the same HIP library (e.g. the -DRT_PROF one)
+        _lib = _load(os.environ.get("RT_AMD_LIBNAME", "librt_amd.so"), ABI)
     return _lib
 
 

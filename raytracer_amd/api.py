@@ -116,7 +116,11 @@ class Context:
             self.set_stream(stream)
 
     def set_stream(self, stream):
-        check(_ffi.lib().rt_ctx_set_stream(self._ctx, C.c_void_p(stream) if stream else None))
+        """stream: a hipStream_t handle as an int (0 = HIP's null stream), or None = the context's own stream."""
+        if stream is None:
+            check(_ffi.lib().rt_ctx_use_own_stream(self._ctx))
+        else:
+            check(_ffi.lib().rt_ctx_set_stream(self._ctx, C.c_void_p(int(stream))))
 
     def synchronize(self):
         check(_ffi.lib().rt_ctx_synchronize(self._ctx))

@@ -10,16 +10,27 @@
 
 #include "rt_device_math.hpp"
 
+#ifndef RT_PRIM_SRC
+#define RT_PRIM_SRC 0 // 0: scalar loads, 1: uniform vector loads, 2: LDS (experiments; 0 ships)
+#endif
+
 namespace rt2d {
 using namespace rtd;
 
 enum { MAT_EMISSIVE = 0, MAT_DIRECTIONAL = 1, MAT_DIFFUSE = 2, MAT_REFLECTIVE = 3, MAT_DIELECTRIC = 4 };
 
 struct MatDev {
-    int32_t kind, ior_kind;
-    double ior_a, ior_b, angle, d;
+    int32_t kind;
+    int32_t ior_row;  // Dielectric: row of the per-wavelength ior tables
+    double angle, d;  // DirectionalEmissive
     int32_t spectrum;
     int32_t black; // Diffuse whose spectrum is all zero (`absorption == Spectrum::default()`, librt2d_reverse.rs:212)
+};
+
+// Circle as the f32 filter sees it: centre rounded to f32 and the padded squared
+// radius r2e (see filter_word).
+struct Circle32 {
+    float cx, cy, r2q, pad_;
 };
 
 // Scene in HBM, struct-of-arrays.  Slot order: circles by ascending pid, then
@@ -27,6 +38,11 @@ struct MatDev {
 // reference recomputes in every hit test (rt_common.rs:83, :244).
 struct SceneDev {
     int32_t n_circ, n_seg, n_obj, pad_;
+    const Circle32 *c32;
+    const Circle32 *lds_c32; // experiment: circles staged in LDS
+    float filt_eb, pad2_; // bound on the f32 error of d.(o-c)
+    double filt_cmax;      // the f32 filter is proven for |origin|_inf <= filt_cmax and |dir|^2 <= 2
+    const double *ior, *inv_ior; // [n_ior][95]: Ior::ior(lambda_i) and its reciprocal (rt_common.rs:442-450)
     const double *ccx, *ccy, *cr2;
     const double *sax, *say, *ssx, *ssy, *snx, *sny;
     const int32_t *cobj, *cpid, *sobj, *spid;
@@ -73,38 +89,61 @@ RT_DEV bool segment_t(double ox, double oy, double rx, double ry, double ax, dou
 // ---------------------------------------------------------------------------
 // Nearest hit over the whole scene, brute force, in two phases per tile of 256
 // slots:
-//  phase 1 (uniform loop, every lane x every primitive): the reference's own
-//    f64 products and sums up to the discriminant (circle) or the three cross
-//    products (segment), then SIGN-BIT logic only — no sqrt, no division, no
-//    compare — marks the lanes for which the primitive can still be a hit.
-//    The filter never drops a true hit:
-//      circle : the reference rejects delta < 0, and with b >= 0 and c >= 0 both
-//               roots are <= 0 (sqrt(delta) <= sqrt(fl(b*b)) = b); the filter
-//               keeps delta' >= 0 && (b' < 0 || c < 0) where b' = b/2 and
-//               delta' = delta/4 are exact power-of-two rescalings (radii are
-//               validated >= 2^-400 so no term of delta underflows unequally).
-//      segment: t = tn/den >= 0 and 0 <= u = un/den <= 1 fail for sure when tn
-//               (or un) is not tiny (|.| >= 2^-900) and differs in sign from den,
-//               or when |un| exceeds |den| by more than 2^-20 relative; scene
-//               and ray magnitudes are validated so |den| <= 2^62 and such a
-//               quotient cannot round to -0.0.
+//  phase 1 (uniform loop, every lane x every primitive; primitives arrive as
+//    scalar operands): a cheap test marks the lanes for which the primitive can
+//    still be a hit.  It decides with SIGN BITS only (no sqrt, division or
+//    compare) and it never drops a hit the reference would report:
+//    circle, in f32 with fused ops: with oc = o - c, bp = d.oc, l2 = |oc|^2 the
+//      reference needs D = bp^2 - l2 + r^2 >= 0 (its delta / 4) and a positive
+//      root, and has no positive root when bp >= 0 and l2 >= r^2.  Rounding o, c, d
+//      to f32 moves each component of oc by at most DELTA = 2^-22 * cmax * 1.001
+//      (|o|, |c| <= cmax per component) and, with |d|^2 <= 2,
+//        |bp_f - bp| <= 2.002 DELTA + 2.53e-7 |oc|  (< eb = 2^-19 cmax),
+//        |bp_f^2 - bp^2| + |l2_f - l2| + roundings <= 8.52 DELTA |oc| + 10.1 DELTA^2 + 1.1e-6 l2 + 1.2e-7 r^2.
+//      The test computes g = q bp_f^2 + q r2e - l2_f, q = 1 / (1 - 2^-17), i.e.
+//      q times (bp_f^2 + r2e - (1 - 2^-17) l2_f), with r2e = r^2 (1 + 2^-22) +
+//      3.0e6 DELTA^2 and q r2e rounded up (the factor q rides on the direction,
+//      pre-scaled by sqrt(q), which adds 2.4e-7 l2 to the bound); since
+//      8.52 DELTA |oc| <= 2.88e6 DELTA^2 + 6.3e-6 l2, g >= 0 whenever D >= 0.  A
+//      circle is also dropped when sqrt(q) bp_f > eb (so bp > 0) and q r2e <= l2_f
+//      (so l2 > r^2): both of the reference's roots are then <= 0.
+//      Lanes whose origin or direction lies outside those bounds mark every slot.
+//    segment, exact f64: the reference's own three cross products; t = tn/den >= 0
+//      and 0 <= u = un/den <= 1 fail for sure when tn (or un) is not tiny
+//      (|.| >= 2^-900) and differs in sign from den, or when |un| exceeds |den| by
+//      more than 2^-20 relative; scene and ray magnitudes are validated so
+//      |den| <= 2^62 and such a quotient cannot round to -0.0.
 //  phase 2 (per-lane loop over its marked slots, ascending): the exact test in
 //    the reference's operation order, then (total_cmp key, pid) lexicographic
 //    minimum = "first minimum in scan order" (librt2d_reverse.rs:139).
 // Inactive lanes run phase 1 with the wave and skip phase 2.
-RT_DEV uint32_t filter_word(const SceneDev &S, int lo, int hi, double ox, double oy, double dx, double dy)
+RT_DEV uint32_t filter_word(const SceneDev &S, int lo, int hi, double ox, double oy, double dx, double dy, float oxf,
+                            float oyf, float dxq, float dyq, uint32_t force)
 {
     uint32_t acc = 0;
     const int c_end = hi < S.n_circ ? hi : S.n_circ;
-#pragma unroll 2
+    const float eb = S.filt_eb;
+#if RT_PRIM_SRC == 1
+    int zero;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(zero));
+#endif
+#pragma unroll 4
     for (int s = lo; s < c_end; ++s) {
-        const double cx = S.ccx[s], cy = S.ccy[s], r2 = S.cr2[s];
-        const double ocx = ox - cx, ocy = oy - cy;
-        const double bp = dx * ocx + dy * ocy;
-        const double cc = (ocx * ocx + ocy * ocy) - r2;
-        const double dl = bp * bp - cc;
-        // keep iff !sign(dl) && (sign(bp) || sign(cc))
-        const uint32_t keep = (uint32_t)(~hi32(dl) & (hi32(bp) | hi32(cc)));
+#if RT_PRIM_SRC == 1
+        const Circle32 c = S.c32[s + zero];
+#elif RT_PRIM_SRC == 2
+        const Circle32 c = S.lds_c32[s];
+#else
+        const Circle32 c = S.c32[s];
+#endif
+        const float ocx = oxf - c.cx, ocy = oyf - c.cy;
+        const float bq = __builtin_fmaf(dxq, ocx, dyq * ocy); // d.oc * sqrt(q)
+        const float l2 = __builtin_fmaf(ocx, ocx, ocy * ocy);
+        const float inner = c.r2q - l2;                    // ~ (r^2 - |oc|^2 / q) q, padded upward
+        const float g = __builtin_fmaf(bq, bq, inner);     // ~ q * discriminant / 4, padded upward
+        const float fb = eb - bq;                          // sign set: surely moving away from the centre
+        // keep iff g >= 0 and not (moving away and origin surely outside)
+        const uint32_t keep = ~__float_as_uint(g) & (~__float_as_uint(fb) | ~__float_as_uint(inner));
         acc = __builtin_amdgcn_alignbit(acc, keep, 31);
     }
     const int s_lo = lo > S.n_circ ? lo : S.n_circ;
@@ -127,10 +166,10 @@ RT_DEV uint32_t filter_word(const SceneDev &S, int lo, int hi, double ox, double
         const uint32_t rej = rej_t | rej_u0 | rej_u1;
         acc = __builtin_amdgcn_alignbit(acc, ~rej, 31);
     }
-    return acc << (32 - (hi - lo));
+    return (acc << (32 - (hi - lo))) | force;
 }
 
-RT_DEV Hit nearest_hit(const SceneDev &S, double ox, double oy, double dx, double dy, bool active)
+RT_DEV Hit nearest_hit(const SceneDev &S, double ox, double oy, double dx, double dy, bool active, Prof &prof)
 {
     Hit best;
     best.t = 0.0;
@@ -138,17 +177,26 @@ RT_DEV Hit nearest_hit(const SceneDev &S, double ox, double oy, double dx, doubl
     best.pid = 0x7fffffff;
     int64_t best_key = 0x7fffffffffffffffLL;
     const int P = S.n_circ + S.n_seg;
+    // q = 1 / (1 - 2^-17); the direction is pre-scaled by sqrt(q) so that (d.oc)^2 arrives multiplied by q
+    constexpr double SQRT_Q = 1.0000038147190937;
+    const float oxf = (float)ox, oyf = (float)oy, dxq = (float)(dx * SQRT_Q), dyq = (float)(dy * SQRT_Q);
+    // outside the range the f32 filter is proven for: every slot becomes a candidate (exact tests decide)
+    const bool in_range = __builtin_fabs(ox) <= S.filt_cmax && __builtin_fabs(oy) <= S.filt_cmax && dx * dx + dy * dy <= 2.0;
+    const uint32_t force = in_range ? 0u : 0xFFFFFFFFu;
     for (int base = 0; base < P; base += 256) {
         uint32_t m[8];
 #pragma unroll
         for (int w = 0; w < 8; ++w) {
             const int lo = base + 32 * w;
             const int hi = (lo + 32 < P) ? lo + 32 : P;
-            m[w] = (lo < P) ? filter_word(S, lo, hi, ox, oy, dx, dy) : 0u;
+            // bits below the word's last slot are shifted-in zeros; `force` may set them, so mask to the valid slots
+            const uint32_t valid = 0xFFFFFFFFu << (32 - ((lo < P) ? hi - lo : 32));
+            m[w] = (lo < P) ? (filter_word(S, lo, hi, ox, oy, dx, dy, oxf, oyf, dxq, dyq, force) & valid) : 0u;
         }
         uint64_t m0 = ((uint64_t)m[0] << 32) | m[1], m1 = ((uint64_t)m[2] << 32) | m[3];
         uint64_t m2 = ((uint64_t)m[4] << 32) | m[5], m3 = ((uint64_t)m[6] << 32) | m[7];
         if (!active) { m0 = m1 = m2 = m3 = 0; }
+        RT_STAMP(prof, 1);
         while ((m0 | m1 | m2 | m3) != 0) {
             const int w = m0 ? 0 : m1 ? 1 : m2 ? 2 : 3;
             const uint64_t cur = m0 ? m0 : m1 ? m1 : m2 ? m2 : m3;
@@ -180,6 +228,7 @@ RT_DEV Hit nearest_hit(const SceneDev &S, double ox, double oy, double dx, doubl
                 }
             }
         }
+        RT_STAMP(prof, 2);
     }
     return best;
 }
@@ -231,12 +280,10 @@ RT_DEV ShadeResult shade(const SceneDev &S, Path &p, const Hit &h, int recursion
     }
     const MatDev m = S.mats[obj];
     const float sv = S.spectra[m.spectrum * NBINS + p.li];
-    const double lambda = (double)p.li * 5.0 + 360.0;
     if (!outside) {
         if (m.kind == MAT_EMISSIVE) { value = sv; return SHADE_DONE; }
         if (m.kind != MAT_DIELECTRIC) return SHADE_DONE;
-        const double l = lambda / 1000.0;
-        const double ior = (m.ior_kind == 0) ? m.ior_a : m.ior_a + m.ior_b / (l * l);
+        const double ior = S.ior[m.ior_row * NBINS + p.li];
         const double qx = hx + nx * 10000.0 * EPS64, qy = hy + ny * 10000.0 * EPS64;
         const double mx = -nx, my = -ny;
         // glam refract(self = dir, normal = -n, eta = ior)
@@ -302,10 +349,8 @@ RT_DEV ShadeResult shade(const SceneDev &S, Path &p, const Hit &h, int recursion
         return SHADE_CONTINUE;
     }
     case MAT_DIELECTRIC: {
-        const double l = lambda / 1000.0;
-        const double ior = (m.ior_kind == 0) ? m.ior_a : m.ior_a + m.ior_b / (l * l);
         const double qx = hx - nx * 100000.0 * EPS64, qy = hy - ny * 100000.0 * EPS64;
-        const double eta = 1.0 / ior;
+        const double eta = S.inv_ior[m.ior_row * NBINS + p.li]; // 1. / ior
         const double ndi = nx * p.dx + ny * p.dy;
         const double kk = 1.0 - eta * eta * (1.0 - ndi * ndi);
         double rx, ry;

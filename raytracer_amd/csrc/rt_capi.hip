@@ -219,7 +219,15 @@ int32_t rt_ctx_set_stream(rt_ctx *ctx, void *hip_stream)
 {
     if (int32_t rc = ctx_bind(ctx)) return rc;
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    ctx->stream = (hipStream_t)hip_stream;
+    return RT_OK;
+}
+
+int32_t rt_ctx_use_own_stream(rt_ctx *ctx)
+{
+    if (int32_t rc = ctx_bind(ctx)) return rc;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ctx->stream = ctx->own_stream;
     return RT_OK;
 }
 
@@ -309,8 +317,34 @@ int32_t rt2d_scene_create(rt_ctx *ctx, const rt2d_scene_desc *d, rt2d_scene **ou
     std::sort(corder.begin(), corder.end(), [&](int a, int b) { return d->circle_pid[a] < d->circle_pid[b]; });
     std::sort(sorder.begin(), sorder.end(), [&](int a, int b) { return d->seg_pid[a] < d->seg_pid[b]; });
 
+    // per-wavelength ior tables, one row per distinct Ior (Ior::ior, rt_common.rs:442-450)
+    struct IorKey { int kind; double a, b; };
+    std::vector<IorKey> iors;
+    std::vector<int> ior_row((size_t)std::max(no, 1), 0);
+    for (int i = 0; i < no; ++i) {
+        const rt2d_material &m = d->materials[i];
+        if (m.kind != RT_MAT_DIELECTRIC) continue;
+        int row = -1;
+        for (size_t k = 0; k < iors.size(); ++k)
+            if (iors[k].kind == m.ior_kind && iors[k].a == m.ior_a && (m.ior_kind == 0 || iors[k].b == m.ior_b)) row = (int)k;
+        if (row < 0) { row = (int)iors.size(); iors.push_back(IorKey{ m.ior_kind, m.ior_a, m.ior_b }); }
+        ior_row[(size_t)i] = row;
+    }
+    const int nior = (int)iors.size();
+
+    // bounds of the f32 circle filter (see rt2d_device.hpp): origins up to twice the scene's extent
+    double abs_max = 1.0;
+    for (int i = 0; i < nc; ++i) abs_max = std::max(abs_max, std::max(std::fabs(d->circle_cx[i]), std::fabs(d->circle_cy[i])));
+    for (int i = 0; i < ns; ++i)
+        abs_max = std::max(abs_max, std::max(std::max(std::fabs(d->seg_ax[i]), std::fabs(d->seg_ay[i])),
+                                             std::max(std::fabs(d->seg_bx[i]), std::fabs(d->seg_by[i]))));
+    const double cmax = 2.0 * abs_max;
+    const double delta = 0x1.0p-22 * cmax * 1.001;
+
     Carver sz{ nullptr };
     auto layout = [&](Carver &c, rt2d::SceneDev &S, std::vector<char> *host) {
+        rt2d::Circle32 *c32 = c.take<rt2d::Circle32>(nc);
+        double *iort = c.take<double>((size_t)nior * RT_NBINS), *inv_iort = c.take<double>((size_t)nior * RT_NBINS);
         double *ccx = c.take<double>(nc), *ccy = c.take<double>(nc), *cr2 = c.take<double>(nc);
         double *sax = c.take<double>(ns), *say = c.take<double>(ns), *ssx = c.take<double>(ns), *ssy = c.take<double>(ns);
         double *snx = c.take<double>(ns), *sny = c.take<double>(ns);
@@ -322,12 +356,27 @@ int32_t rt2d_scene_create(rt_ctx *ctx, const rt2d_scene_desc *d, rt2d_scene **ou
             auto H = [&](auto *p) { return reinterpret_cast<decltype(p)>(hb + (reinterpret_cast<char *>(p) - c.base)); };
             for (int k = 0; k < nc; ++k) {
                 const int i = corder[(size_t)k];
+                const double r2 = d->circle_r[i] * d->circle_r[i]; // r.powi(2), rt_common.rs:76,83
                 H(ccx)[k] = d->circle_cx[i];
                 H(ccy)[k] = d->circle_cy[i];
-                H(cr2)[k] = d->circle_r[i] * d->circle_r[i]; // r.powi(2), rt_common.rs:76,83
+                H(cr2)[k] = r2;
                 H(cobj)[k] = d->circle_obj[i];
                 H(cpid)[k] = d->circle_pid[i];
+                rt2d::Circle32 c3{};
+                c3.cx = (float)d->circle_cx[i];
+                c3.cy = (float)d->circle_cy[i];
+                const double q = 1.0 / (1.0 - 0x1.0p-17);
+                c3.r2q = std::nextafterf((float)((r2 * (1.0 + 0x1.0p-22) + 3.0e6 * delta * delta) * q), INFINITY);
+                H(c32)[k] = c3;
             }
+            for (int k = 0; k < nior; ++k)
+                for (int b = 0; b < RT_NBINS; ++b) {
+                    const double lambda = (double)b * 5.0 + 360.0; // spectrum.rs:185-191
+                    const double l = lambda / 1000.0;
+                    const double ior = (iors[(size_t)k].kind == 0) ? iors[(size_t)k].a : iors[(size_t)k].a + iors[(size_t)k].b / (l * l);
+                    H(iort)[k * RT_NBINS + b] = ior;
+                    H(inv_iort)[k * RT_NBINS + b] = 1.0 / ior; // `1. / ior`, librt2d_reverse.rs:249
+                }
             for (int k = 0; k < ns; ++k) {
                 const int i = sorder[(size_t)k];
                 H(sax)[k] = d->seg_ax[i];
@@ -342,8 +391,9 @@ int32_t rt2d_scene_create(rt_ctx *ctx, const rt2d_scene_desc *d, rt2d_scene **ou
             for (int i = 0; i < no; ++i) {
                 const rt2d_material &m = d->materials[i];
                 rt2d::MatDev md{};
-                md.kind = m.kind; md.ior_kind = m.ior_kind;
-                md.ior_a = m.ior_a; md.ior_b = m.ior_b; md.angle = m.angle; md.d = m.d;
+                md.kind = m.kind;
+                md.ior_row = ior_row[(size_t)i];
+                md.angle = m.angle; md.d = m.d;
                 md.spectrum = (m.kind == RT_MAT_REFLECTIVE) ? 0 : m.spectrum;
                 md.black = 0;
                 if (m.kind == RT_MAT_DIFFUSE) {
@@ -357,6 +407,12 @@ int32_t rt2d_scene_create(rt_ctx *ctx, const rt2d_scene_desc *d, rt2d_scene **ou
             if (nsp) memcpy(H(spectra), d->spectra, sizeof(float) * (size_t)nsp * RT_NBINS);
         }
         S.n_circ = nc; S.n_seg = ns; S.n_obj = no; S.pad_ = 0;
+        S.c32 = c32;
+        S.lds_c32 = nullptr;
+        S.pad2_ = 0.0f;
+        S.filt_eb = std::nextafterf((float)(0x1.0p-19 * cmax), INFINITY);
+        S.filt_cmax = cmax;
+        S.ior = iort; S.inv_ior = inv_iort;
         S.ccx = ccx; S.ccy = ccy; S.cr2 = cr2;
         S.sax = sax; S.say = say; S.ssx = ssx; S.ssy = ssy; S.snx = snx; S.sny = sny;
         S.cobj = cobj; S.cpid = cpid; S.sobj = sobj; S.spid = spid;
@@ -432,6 +488,15 @@ int32_t launch_render2d(rt_ctx *ctx, const rt2d_scene *scene, const rt2d_render_
     A.out = d_out;
     A.ray_counter = ctx->d_rays;
     A.refill_min = refill_threshold(scene->n_prims);
+    A.prof_out = nullptr;
+#ifdef RT_PROF
+    {
+        static unsigned long long *d_prof = nullptr;
+        if (!d_prof) { HIP_TRY(hipMalloc((void **)&d_prof, 8 * sizeof(unsigned long long))); }
+        HIP_TRY(hipMemsetAsync(d_prof, 0, 8 * sizeof(unsigned long long), ctx->stream));
+        A.prof_out = d_prof;
+    }
+#endif
     int64_t tiles = list_mode ? (n_list + rtk::TILE_PIXELS - 1) / rtk::TILE_PIXELS
                               : (int64_t)A.tiles_x * ((p->height + 7) / 8);
     if (tiles <= 0) return RT_OK;
@@ -445,6 +510,16 @@ int32_t launch_render2d(rt_ctx *ctx, const rt2d_scene *scene, const rt2d_render_
     HIP_TRY(hipEventRecord(ev.second, ctx->stream));
     ctx->pending.push_back(ev);
     ctx->launches += 1;
+#ifdef RT_PROF
+    {
+        unsigned long long h[8];
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        HIP_TRY(hipMemcpy(h, A.prof_out, sizeof h, hipMemcpyDeviceToHost));
+        const double tot = (double)(h[0] + h[1] + h[2] + h[3] + h[4]);
+        fprintf(stderr, "[rt_prof] regen %.3f phase1 %.3f phase2 %.3f shade %.3f loop %.3f | wave_steps %llu lanes/step %.2f cycles/step %.0f\n",
+                h[0] / tot, h[1] / tot, h[2] / tot, h[3] / tot, h[4] / tot, h[5], (double)h[6] / (double)h[5], tot / (double)h[5]);
+    }
+#endif
     const int64_t npx = list_mode ? n_list : (int64_t)p->width * p->height;
     ctx->samples += (uint64_t)npx * (uint64_t)p->spp * (uint64_t)p->lambda_samples;
     return RT_OK;

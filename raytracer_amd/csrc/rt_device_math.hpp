@@ -28,11 +28,11 @@ RT_DEV U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint
 {
 #pragma unroll
     for (int round = 0; round < 10; ++round) {
-        const uint32_t lo0 = 0xD2511F53u * c0, hi0 = __umulhi(0xD2511F53u, c0);
-        const uint32_t lo1 = 0xCD9E8D57u * c2, hi1 = __umulhi(0xCD9E8D57u, c2);
-        const uint32_t n0 = hi1 ^ c1 ^ k0;
-        const uint32_t n2 = hi0 ^ c3 ^ k1;
-        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0; // one v_mad_u64_u32 each
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        c0 = n0; c1 = (uint32_t)p1; c2 = n2; c3 = (uint32_t)p0;
         k0 += 0x9E3779B9u;
         k1 += 0xBB67AE85u;
     }
@@ -42,8 +42,8 @@ RT_DEV U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint
 // 53-bit uniform in [0,1): ((hi:lo) >> 11) * 2^-53, as rand's f64 sampling does.
 RT_DEV double u01(uint32_t lo, uint32_t hi)
 {
-    const uint64_t v = ((uint64_t)hi << 32) | lo;
-    return (double)(v >> 11) * 0x1.0p-53;
+    // hi * 2^-32 + (lo >> 11) * 2^-53: both conversions, the product and the sum are exact
+    return __builtin_fma((double)hi, 0x1.0p-32, (double)(lo >> 11) * 0x1.0p-53);
 }
 
 // ---------------------------------------------------------------------------
@@ -120,6 +120,27 @@ RT_DEV int hi32(double x) { return __double2hiint(x); }
 // 1/len with len = sqrt(x.x + y.y): glam's normalize multiplies by the reciprocal.
 RT_DEV double rlen2(double x, double y) { return 1.0 / __builtin_sqrt(x * x + y * y); }
 RT_DEV double rlen3(double x, double y, double z) { return 1.0 / __builtin_sqrt((x * x + y * y) + z * z); }
+
+// Diagnostic build only (-DRT_PROF): per-wave cycle shares of the trace loop's
+// sections, stamped with s_memtime.  Never compiled into the shipped library.
+#ifdef RT_PROF
+struct Prof {
+    unsigned long long t[8];
+    unsigned long long last;
+};
+#define RT_STAMP(prof, i)                                                              \
+    do {                                                                               \
+        __builtin_amdgcn_sched_barrier(0);                                             \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();                  \
+        __builtin_amdgcn_s_waitcnt(0xC07F);                                            \
+        (prof).t[i] += now_ - (prof).last;                                             \
+        (prof).last = now_;                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                             \
+    } while (0)
+#else
+struct Prof {};
+#define RT_STAMP(prof, i) do { } while (0)
+#endif
 
 // wave64 helpers
 RT_DEV int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }

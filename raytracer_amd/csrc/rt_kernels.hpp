@@ -30,6 +30,7 @@ struct Render2dArgs {
     float *out;
     unsigned long long *ray_counter;
     int32_t refill_min; // refill dead lanes once at least this many are dead (1..64)
+    unsigned long long *prof_out; // diagnostic builds only
 };
 
 // ReverseRenderer::compute_pixel for every pixel of a tile
@@ -40,6 +41,15 @@ __global__ __launch_bounds__(BLOCK) void render2d_kernel(const Render2dArgs A)
     __shared__ int next_item;
     const int tid = threadIdx.x;
     const int tile = blockIdx.x;
+#if RT_PRIM_SRC == 2
+    __shared__ rt2d::Circle32 lds_c32[1024];
+    for (int i = tid; i < A.S.n_circ && i < 1024; i += BLOCK) lds_c32[i] = A.S.c32[i];
+    rt2d::SceneDev SS = A.S;
+    SS.lds_c32 = lds_c32;
+#define RT_SCENE SS
+#else
+#define RT_SCENE A.S
+#endif
     for (int i = tid; i < TILE_PIXELS * NBINS; i += BLOCK) acc[i] = 0.0f;
     if (tid == 0) next_item = 0;
     __syncthreads();
@@ -57,8 +67,13 @@ __global__ __launch_bounds__(BLOCK) void render2d_kernel(const Render2dArgs A)
     bool wave_done = false;
     int lpix = 0;
     unsigned long long nrays = 0;
+    Prof prof{};
+#ifdef RT_PROF
+    prof.last = __builtin_amdgcn_s_memtime();
+#endif
 
     while (true) {
+        RT_STAMP(prof, 4);
         const uint64_t dead = __ballot(!alive);
         const int ndead = __popcll(dead);
         if (!wave_done && (ndead >= A.refill_min || ndead == 64)) {
@@ -101,7 +116,12 @@ __global__ __launch_bounds__(BLOCK) void render2d_kernel(const Render2dArgs A)
             continue;
         }
         const bool run = alive && p.depth_left > 0;
-        const rt2d::Hit h = rt2d::nearest_hit(A.S, p.ox, p.oy, p.dx, p.dy, run);
+        RT_STAMP(prof, 0);
+#ifdef RT_PROF
+        prof.t[5] += 1;
+        prof.t[6] += (unsigned long long)__popcll(__ballot(run));
+#endif
+        const rt2d::Hit h = rt2d::nearest_hit(RT_SCENE, p.ox, p.oy, p.dx, p.dy, run, prof);
         if (alive) {
             float value = 0.0f;
             rt2d::ShadeResult r = rt2d::SHADE_DONE;
@@ -121,7 +141,12 @@ __global__ __launch_bounds__(BLOCK) void render2d_kernel(const Render2dArgs A)
                 alive = false; // the recursive call returns 0 at depth 0 (:120-122)
             }
         }
+        RT_STAMP(prof, 3);
     }
+#ifdef RT_PROF
+    if ((tid & 63) == 0 && A.prof_out)
+        for (int i = 0; i < 8; ++i) atomicAdd(A.prof_out + i, prof.t[i]);
+#endif
 
     // rays traced by this wave -> one global atomic
     for (int off = 32; off > 0; off >>= 1) nrays += __shfl_down(nrays, off);
@@ -170,7 +195,8 @@ __global__ __launch_bounds__(BLOCK) void trace_batch2d_kernel(const rt2d::SceneD
     double ft = -1.0;
     while (__any(alive)) {
         const bool run = alive && p.depth_left > 0;
-        const rt2d::Hit h = rt2d::nearest_hit(S, p.ox, p.oy, p.dx, p.dy, run);
+        Prof prof{};
+        const rt2d::Hit h = rt2d::nearest_hit(S, p.ox, p.oy, p.dx, p.dy, run, prof);
         if (alive) {
             if (!run) {
                 alive = false;
