@@ -79,6 +79,7 @@ def main():
 
     import raytracer_amd as rt
     from raytracer_amd.api import params2d
+    from raytracer_amd.sharding import sample_offset, total_spp
 
     world = rt.World2D(args.scene, seed=1)
     stream = torch.cuda.current_stream()
@@ -90,14 +91,14 @@ def main():
 
     def step(i):
         # global sample index: step-major, rank-minor, so no two ranks or steps share a sample
-        off = (i * world_size + rank) * args.spp
+        off = sample_offset(i, rank, world_size, args.spp)
         scene.accumulate(params2d(W, H, args.spp, args.lambda_samples, args.depth, seed=0, sample_offset=off),
                          spectrum.data_ptr())
 
     def finish(n_steps):
         if world_size > 1:
             dist.all_reduce(spectrum, op=dist.ReduceOp.SUM)
-        scene.resolve(spectrum.data_ptr(), W, H, n_steps * args.spp * world_size, d_rgb_ptr=rgb.data_ptr(), to_host=False)
+        scene.resolve(spectrum.data_ptr(), W, H, total_spp(n_steps, world_size, args.spp), d_rgb_ptr=rgb.data_ptr(), to_host=False)
 
     def barrier():
         torch.cuda.synchronize()
