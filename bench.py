@@ -49,6 +49,23 @@ def cpu_baseline(world, p_full, threads, spp_sample):
             "samples_per_s": p.width * p.height * spp_sample * p.lambda_samples / dt}
 
 
+def measured_traffic(workload_is_default):
+    """HBM bytes per launch of the render kernel from the committed rocprofv3 PMC passes (FETCH_SIZE doubled
+    as gfx950 needs, + WRITE_SIZE; separate --pmc runs, tools/profile_r1.sh): only valid for the default workload."""
+    if not workload_is_default:
+        return None
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_*.json")))
+    for f in reversed(files):
+        try:
+            d = json.load(open(f))
+            if d.get("kernel") == "render2d_kernel" and "hbm_bytes_per_launch_corrected" in d["per_dispatch"]:
+                return d["per_dispatch"]["hbm_bytes_per_launch_corrected"]
+        except Exception:
+            continue
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -151,7 +168,9 @@ def main():
             "samples_per_s": total_samples / dt,
             "rays_per_sample": total_rays / max(1.0, total_samples),
             "roofline": {"bound": "valu", "achieved": achieved, "peak": F64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / F64_VECTOR_PEAK_TFLOPS, "traffic": None,
+                         "frac": achieved / F64_VECTOR_PEAK_TFLOPS,
+                         "traffic": measured_traffic((args.scene, W, H, args.spp, args.lambda_samples, args.depth)
+                                                     == ("complex_world", 1920, 1080, 64, 2, 10)),
                          "kernel": "render2d_kernel", "kernel_ms": kernel_ms,
                          "flop_model": f"rays x (15 x {P} + 60), FMA-rate f64 vector peak; the kernel may not fuse "
                                        "(reference arithmetic is unfused), so 0.5 is its ceiling",
