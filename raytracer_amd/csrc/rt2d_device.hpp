@@ -10,10 +10,6 @@
 
 #include "rt_device_math.hpp"
 
-#ifndef RT_PRIM_SRC
-#define RT_PRIM_SRC 0 // 0: scalar loads, 1: uniform vector loads, 2: LDS (experiments; 0 ships)
-#endif
-
 namespace rt2d {
 using namespace rtd;
 
@@ -27,19 +23,15 @@ struct MatDev {
     int32_t black; // Diffuse whose spectrum is all zero (`absorption == Spectrum::default()`, librt2d_reverse.rs:212)
 };
 
-// Circle as the f32 filter sees it: centre rounded to f32 and the padded squared
-// radius r2e (see filter_word).
-struct Circle32 {
-    float cx, cy, r2q, pad_;
-};
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // Scene in HBM, struct-of-arrays.  Slot order: circles by ascending pid, then
 // segments by ascending pid.  cr2 = r*r and (ssx, ssy) = b - a are the values the
 // reference recomputes in every hit test (rt_common.rs:83, :244).
 struct SceneDev {
-    int32_t n_circ, n_seg, n_obj, pad_;
-    const Circle32 *c32;
-    const Circle32 *lds_c32; // experiment: circles staged in LDS
+    int32_t n_circ, n_seg, n_obj, pad_; // n_circ is even: an odd circle count is padded with a circle nothing can hit
+    // circles as the f32 filter sees them (see filter_word): centre rounded to f32, padded squared radius
+    const float *c32x, *c32y, *c32r;
     float filt_eb, pad2_; // bound on the f32 error of d.(o-c)
     double filt_cmax;      // the f32 filter is proven for |origin|_inf <= filt_cmax and |dir|^2 <= 2
     const double *ior, *inv_ior; // [n_ior][95]: Ior::ior(lambda_i) and its reciprocal (rt_common.rs:442-450)
@@ -122,29 +114,27 @@ RT_DEV uint32_t filter_word(const SceneDev &S, int lo, int hi, double ox, double
 {
     uint32_t acc = 0;
     const int c_end = hi < S.n_circ ? hi : S.n_circ;
-    const float eb = S.filt_eb;
-#if RT_PRIM_SRC == 1
-    int zero;
-    asm volatile("v_mov_b32 %0, 0" : "=v"(zero));
-#endif
+    // two circles per packed f32 instruction (v_pk_add/mul/fma_f32): the circle count is padded to even
+    // and word boundaries are even, so a pair never straddles a word
+    float ebv;
+    asm("v_mov_b32 %0, %1" : "=v"(ebv) : "s"(S.filt_eb)); // in a VGPR: a scalar operand costs a VALU op ~2 extra cycles
+    const f32x2 ox2 = { oxf, oxf }, oy2 = { oyf, oyf }, dx2 = { dxq, dxq }, dy2 = { dyq, dyq }, eb2 = { ebv, ebv };
 #pragma unroll 4
-    for (int s = lo; s < c_end; ++s) {
-#if RT_PRIM_SRC == 1
-        const Circle32 c = S.c32[s + zero];
-#elif RT_PRIM_SRC == 2
-        const Circle32 c = S.lds_c32[s];
-#else
-        const Circle32 c = S.c32[s];
-#endif
-        const float ocx = oxf - c.cx, ocy = oyf - c.cy;
-        const float bq = __builtin_fmaf(dxq, ocx, dyq * ocy); // d.oc * sqrt(q)
-        const float l2 = __builtin_fmaf(ocx, ocx, ocy * ocy);
-        const float inner = c.r2q - l2;                    // ~ (r^2 - |oc|^2 / q) q, padded upward
-        const float g = __builtin_fmaf(bq, bq, inner);     // ~ q * discriminant / 4, padded upward
-        const float fb = eb - bq;                          // sign set: surely moving away from the centre
+    for (int s = lo; s < c_end; s += 2) {
+        const f32x2 cx = *reinterpret_cast<const f32x2 *>(S.c32x + s);
+        const f32x2 cy = *reinterpret_cast<const f32x2 *>(S.c32y + s);
+        const f32x2 r2q = *reinterpret_cast<const f32x2 *>(S.c32r + s);
+        const f32x2 ocx = ox2 - cx, ocy = oy2 - cy;
+        const f32x2 bq = __builtin_elementwise_fma(dx2, ocx, dy2 * ocy); // d.oc * sqrt(q)
+        const f32x2 l2 = __builtin_elementwise_fma(ocx, ocx, ocy * ocy);
+        const f32x2 inner = r2q - l2;                                    // ~ (r^2 - |oc|^2 / q) q, padded upward
+        const f32x2 g = __builtin_elementwise_fma(bq, bq, inner);        // ~ q * discriminant / 4, padded upward
+        const f32x2 fb = eb2 - bq;                                       // sign set: surely moving away from the centre
         // keep iff g >= 0 and not (moving away and origin surely outside)
-        const uint32_t keep = ~__float_as_uint(g) & (~__float_as_uint(fb) | ~__float_as_uint(inner));
-        acc = __builtin_amdgcn_alignbit(acc, keep, 31);
+        const uint32_t keep0 = ~__float_as_uint(g.x) & (~__float_as_uint(fb.x) | ~__float_as_uint(inner.x));
+        const uint32_t keep1 = ~__float_as_uint(g.y) & (~__float_as_uint(fb.y) | ~__float_as_uint(inner.y));
+        acc = __builtin_amdgcn_alignbit(acc, keep0, 31);
+        acc = __builtin_amdgcn_alignbit(acc, keep1, 31);
     }
     const int s_lo = lo > S.n_circ ? lo : S.n_circ;
 #pragma unroll 2
@@ -243,135 +233,197 @@ struct Path {
     uint32_t c0, c1, c2; // Philox counter words naming this path
 };
 
-enum ShadeResult { SHADE_CONTINUE = 0, SHADE_DONE = 1 };
+enum ShadeResult { SHADE_CONTINUE = 0, SHADE_DONE = 1, SHADE_DIFFUSE = 2 };
 
 // One trace_ray body after the nearest hit is known (librt2d_reverse.rs:146-261).
 // Returns SHADE_DONE with `value` = the radiance this invocation returns to its
 // caller (to be multiplied by the path's collected factors), or SHADE_CONTINUE
 // with the path advanced to the recursive call's ray.
-RT_DEV ShadeResult shade(const SceneDev &S, Path &p, const Hit &h, int recursion_limit, uint32_t k0, uint32_t k1,
-                         float &value)
+//
+// The reference's side x material switch is regrouped so that a wave runs each
+// expensive piece once: (1) classify, (2) the circle normal (sqrt + divide) for
+// every lane that needs one, (3) one reflect/refract body shared by Reflective,
+// Dielectric entry and Dielectric exit (they differ only in the normal's sign, eta
+// and the offset).  A Diffuse bounce returns SHADE_DIFFUSE with the path moved to
+// its new origin and the surface normal in (dnx, dny); its direction is then drawn
+// by rand_hemisphere_wave, which the whole wave enters together.  Every value is
+// computed with the reference's operations in the reference's order.
+RT_DEV ShadeResult shade(const SceneDev &S, Path &p, const Hit &h, float &value, double &dnx, double &dny, Prof &prof)
 {
     value = 0.0f;
     if (h.slot < 0) return SHADE_DONE;
-    double hx, hy, nx, ny;
+    const bool is_circle = h.slot < S.n_circ;
+    const int k = is_circle ? h.slot : h.slot - S.n_circ;
+    const double hx = p.ox + h.t * p.dx, hy = p.oy + h.t * p.dy; // ray.origin + t * ray.dir
+    double nx = 0.0, ny = 0.0, cx = 0.0, cy = 0.0;
     bool outside;
     int obj;
-    if (h.slot < S.n_circ) {
-        const int s = h.slot;
-        const double cx = S.ccx[s], cy = S.ccy[s];
-        hx = p.ox + h.t * p.dx;
-        hy = p.oy + h.t * p.dy;
-        const double vx = hx - cx, vy = hy - cy;
-        const double rl = rlen2(vx, vy);
-        nx = vx * rl;
-        ny = vy * rl;
-        const double ex = cx - p.ox, ey = cy - p.oy;
-        outside = !((ex * ex + ey * ey) < S.cr2[s]);
-        obj = S.cobj[s];
+    if (is_circle) {
+        cx = S.ccx[k];
+        cy = S.ccy[k];
+        const double ex = cx - p.ox, ey = cy - p.oy; // is_inside(ray.origin), rt_common.rs:75-77
+        outside = !((ex * ex + ey * ey) < S.cr2[k]);
+        obj = S.cobj[k];
     } else {
-        const int k = h.slot - S.n_circ;
-        hx = p.ox + h.t * p.dx;
-        hy = p.oy + h.t * p.dy;
         nx = S.snx[k];
         ny = S.sny[k];
-        outside = (nx * p.dx + ny * p.dy) < 0.0;
+        outside = (nx * p.dx + ny * p.dy) < 0.0; // rt_common.rs:262
         obj = S.sobj[k];
     }
     const MatDev m = S.mats[obj];
     const float sv = S.spectra[m.spectrum * NBINS + p.li];
-    if (!outside) {
-        if (m.kind == MAT_EMISSIVE) { value = sv; return SHADE_DONE; }
-        if (m.kind != MAT_DIELECTRIC) return SHADE_DONE;
-        const double ior = S.ior[m.ior_row * NBINS + p.li];
-        const double qx = hx + nx * 10000.0 * EPS64, qy = hy + ny * 10000.0 * EPS64;
-        const double mx = -nx, my = -ny;
-        // glam refract(self = dir, normal = -n, eta = ior)
-        const double ndi = mx * p.dx + my * p.dy;
-        const double kk = 1.0 - ior * ior * (1.0 - ndi * ndi);
-        double rx, ry;
-        bool tir = true;
-        if (kk >= 0.0) {
-            const double mm = ior * ndi + __builtin_sqrt(kk);
-            rx = ior * p.dx - mm * mx;
-            ry = ior * p.dy - mm * my;
-            tir = (rx == 0.0 && ry == 0.0);
-        }
-        if (tir) {
-            const double k2 = 2.0 * (p.dx * mx + p.dy * my);
-            rx = p.dx - k2 * mx;
-            ry = p.dy - k2 * my;
-        }
-        p.thr = p.thr * expf_fixed((float)(-h.t) * sv);
-        p.ox = qx; p.oy = qy; p.dx = rx; p.dy = ry;
-        p.depth_left -= 1;
-        return SHADE_CONTINUE;
+
+    // (1) classify
+    enum { TERM, DIRECTIONAL, DIFFUSE, BEND };
+    int act = TERM;
+    if (m.kind == MAT_EMISSIVE) value = sv;                       // either side (:148, :225)
+    else if (m.kind == MAT_DIELECTRIC) act = BEND;                // either side (:149-160, :246-257)
+    else if (outside && m.kind == MAT_REFLECTIVE) act = BEND;     // :238-245
+    else if (outside && m.kind == MAT_DIFFUSE && !m.black) act = DIFFUSE; // :211-224
+    else if (outside && m.kind == MAT_DIRECTIONAL) act = DIRECTIONAL;     // :226-237
+    if (act == TERM) return SHADE_DONE; // emitted, or one of the reference's `_ => 0` arms
+    RT_STAMP(prof, 7);
+
+    // (2) Circle::hit's normal: (p - center).normalize(), always outward (rt_common.rs:103)
+    if (is_circle) {
+        const double vx = hx - cx, vy = hy - cy;
+        const double rl = rlen2(vx, vy);
+        nx = vx * rl;
+        ny = vy * rl;
     }
-    switch (m.kind) {
-    case MAT_DIFFUSE: {
-        if (m.black) return SHADE_DONE;
-        const double qx = hx + nx * 10000.0 * EPS64, qy = hy + ny * 10000.0 * EPS64;
-        const uint32_t bounce = (uint32_t)(recursion_limit - p.depth_left);
-        double vx, vy;
-        for (uint32_t attempt = 0;; ++attempt) {
-            const U4 w = philox4x32_10(p.c0, p.c1, p.c2, (bounce << 20) | (attempt & 0xFFFFFu), k0, k1);
-            vx = u01(w.x, w.y) * 2.0 - 1.0;
-            vy = u01(w.z, w.w) * 2.0 - 1.0;
-            if (vx * vx + vy * vy <= 1.0) {
-                const double rl = rlen2(vx, vy);
-                vx = vx * rl;
-                vy = vy * rl;
-                if (vx * nx + vy * ny > 0.0) break;
-            }
-        }
-        p.thr = p.thr * sv;
-        p.ox = qx; p.oy = qy; p.dx = vx; p.dy = vy;
-        p.depth_left -= 1;
-        return SHADE_CONTINUE;
-    }
-    case MAT_EMISSIVE:
-        value = sv;
-        return SHADE_DONE;
-    case MAT_DIRECTIONAL: {
-        const double mx = -nx, my = -ny;
-        if (p.dx * mx + p.dy * my >= m.angle) {
+
+    RT_STAMP(prof, 8);
+    if (act == DIRECTIONAL) {
+        if (p.dx * -nx + p.dy * -ny >= m.angle) {
             const double coeff = 1.0 / (h.t + m.d);
             value = sv * (float)coeff;
         }
         return SHADE_DONE;
     }
-    case MAT_REFLECTIVE: {
-        const double qx = hx + nx * 10000.0 * EPS64, qy = hy + ny * 10000.0 * EPS64;
-        const double k2 = 2.0 * (p.dx * nx + p.dy * ny);
-        const double rx = p.dx - k2 * nx, ry = p.dy - k2 * ny;
-        p.ox = qx; p.oy = qy; p.dx = rx; p.dy = ry;
-        p.depth_left -= 1;
-        return SHADE_CONTINUE;
-    }
-    case MAT_DIELECTRIC: {
-        const double qx = hx - nx * 100000.0 * EPS64, qy = hy - ny * 100000.0 * EPS64;
-        const double eta = S.inv_ior[m.ior_row * NBINS + p.li]; // 1. / ior
-        const double ndi = nx * p.dx + ny * p.dy;
-        const double kk = 1.0 - eta * eta * (1.0 - ndi * ndi);
-        double rx, ry;
-        bool tir = true;
-        if (kk >= 0.0) {
-            const double mm = eta * ndi + __builtin_sqrt(kk);
-            rx = eta * p.dx - mm * nx;
-            ry = eta * p.dy - mm * ny;
-            tir = (rx == 0.0 && ry == 0.0);
+
+    double rx, ry, qx, qy;
+    if (act == BEND) {
+        const bool diel = m.kind == MAT_DIELECTRIC;
+        const bool entering = diel && outside;
+        // new origin: p - n*1e5*eps when entering glass (:248), p + n*1e4*eps otherwise (:151, :240)
+        const double kofs = entering ? 100000.0 : 10000.0;
+        const double tx = nx * kofs * EPS64, ty = ny * kofs * EPS64;
+        qx = entering ? hx - tx : hx + tx;
+        qy = entering ? hy - ty : hy + ty;
+        // the normal the reference passes to refract / reflect: -n from inside, n from outside
+        const double Nx = outside ? nx : -nx, Ny = outside ? ny : -ny;
+        const double ndi = Nx * p.dx + Ny * p.dy;
+        bool bounce = true;
+        if (diel) {
+            // glam refract(dir, N, eta); eta = ior leaving (:150-152), 1/ior entering (:247-249)
+            const double eta = outside ? S.inv_ior[m.ior_row * NBINS + p.li] : S.ior[m.ior_row * NBINS + p.li];
+            const double kk = 1.0 - eta * eta * (1.0 - ndi * ndi);
+            if (kk >= 0.0) {
+                const double mm = eta * ndi + __builtin_sqrt(kk);
+                rx = eta * p.dx - mm * Nx;
+                ry = eta * p.dy - mm * Ny;
+                bounce = (rx == 0.0 && ry == 0.0); // `refracted_ray == DVec2::ZERO`
+            }
+            if (!outside) p.thr = p.thr * expf_fixed((float)(-h.t) * sv); // Beer-Lambert on the way out (:159)
         }
-        if (tir) {
-            const double k2 = 2.0 * (p.dx * nx + p.dy * ny);
-            rx = p.dx - k2 * nx;
-            ry = p.dy - k2 * ny;
+        if (bounce) {
+            // glam reflect: dir - 2 * dir.dot(N) * N   (dir.dot(N) has the bits of N.dot(dir))
+            const double k2 = 2.0 * ndi;
+            rx = p.dx - k2 * Nx;
+            ry = p.dy - k2 * Ny;
         }
-        p.ox = qx; p.oy = qy; p.dx = rx; p.dy = ry;
+        RT_STAMP(prof, 9);
+    } else {
+        // Diffuse (:211-224): new origin p + n*1e4*eps, factor `absorption[lambda]`; direction drawn by the wave
+        p.ox = hx + nx * 10000.0 * EPS64;
+        p.oy = hy + ny * 10000.0 * EPS64;
+        p.thr = p.thr * sv;
         p.depth_left -= 1;
-        return SHADE_CONTINUE;
+        dnx = nx;
+        dny = ny;
+        return SHADE_DIFFUSE;
     }
-    default:
-        return SHADE_DONE;
+    p.ox = qx; p.oy = qy; p.dx = rx; p.dy = ry;
+    p.depth_left -= 1;
+    return SHADE_CONTINUE;
+}
+
+// Ray2d::rand_hemisphere (rt_common.rs:376-391) for every lane with `need`, entered by the whole wave.
+//
+// The reference loops per ray: draw v in [-1,1)^2, keep it if |v|^2 <= 1 and v.normalize().dot(n) > 0.
+// Attempt k of a path takes its two numbers from Philox(counter = path words, bounce << 20 | k), so ANY
+// lane can evaluate it.  With nd lanes needing a direction, each gets H = 64 / nd helper lanes that test
+// attempts base .. base+H-1 at once; the lowest accepted attempt wins (the same vector the sequential
+// loop would stop at) and is shuffled back.  A handful of diffuse lanes would otherwise hold the wave
+// for the maximum of their geometric trial counts (~6 rounds at 39 % acceptance) at < 10 % lane use.
+//
+// Acceptance without the square root: `v.normalize().dot(n) > 0` has the sign of the unnormalised
+// a + b = v.x n.x + v.y n.y whenever |a + b| > 2^-40 (|a| + |b|) (the normalised sum differs from
+// (a + b)/|v| by less than 2^-50 (|a| + |b|)/|v|); closer calls evaluate the reference's own expression.
+// The accepted vector is normalised once, as the reference does: v * (1 / sqrt(v.v)).
+RT_DEV void rand_hemisphere_wave(bool need, double nx, double ny, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t bounce,
+                                 uint32_t k0, uint32_t k1, double &rx, double &ry)
+{
+    uint64_t pending = __ballot(need);
+    if (pending == 0) return;
+    const int lane = lane_id();
+    bool still = need;
+    uint32_t base = 0;
+    double ovx = 0.0, ovy = 0.0, ol2 = 1.0;
+    while (pending != 0) {
+        const int nd = __popcll(pending);
+        const int H = 64 / nd; // >= 1, wave-uniform
+        int tl = lane, toff = 0;
+        bool helper = still;
+        if (H >= 2) {
+            const int trank = lane / H;
+            toff = lane - trank * H;
+            helper = trank < nd;
+            uint64_t m = pending; // the trank-th set bit of `pending` is the lane this one helps
+            for (int r = 0; m != 0; ++r) {
+                const int b = __ffsll((long long)m) - 1;
+                m &= m - 1;
+                tl = (trank == r) ? b : tl;
+            }
+        }
+        const uint32_t tc0 = __shfl(c0, tl), tc1 = __shfl(c1, tl), tc2 = __shfl(c2, tl);
+        const uint32_t tb = __shfl(bounce, tl), tbase = __shfl(base, tl);
+        const double tnx = __shfl(nx, tl), tny = __shfl(ny, tl);
+        const uint32_t attempt = tbase + (uint32_t)toff;
+        const U4 w = philox4x32_10(tc0, tc1, tc2, (tb << 20) | (attempt & 0xFFFFFu), k0, k1);
+        const double vx = u01(w.x, w.y) * 2.0 - 1.0;
+        const double vy = u01(w.z, w.w) * 2.0 - 1.0;
+        const double l2 = vx * vx + vy * vy;
+        bool ok = false;
+        if (helper && l2 <= 1.0) {
+            const double a = vx * tnx, b = vy * tny;
+            const double du = a + b;
+            if (__builtin_fabs(du) > 0x1.0p-40 * (__builtin_fabs(a) + __builtin_fabs(b))) {
+                ok = du > 0.0;
+            } else {
+                const double rl = 1.0 / __builtin_sqrt(l2);
+                ok = (vx * rl) * tnx + (vy * rl) * tny > 0.0;
+            }
+        }
+        const uint64_t okm = __ballot(ok);
+        // a pending lane reads the verdicts of its own helpers: bits [rank * H, rank * H + H)
+        const int seg_lo = (H >= 2) ? rank_in_mask(pending) * H : lane;
+        const uint64_t seg_mask = (H >= 64) ? ~0ull : ((1ull << H) - 1ull);
+        const uint64_t seg = still ? ((okm >> seg_lo) & seg_mask) : 0ull;
+        const int winner = seg ? seg_lo + (__ffsll((long long)seg) - 1) : lane;
+        const double wvx = __shfl(vx, winner), wvy = __shfl(vy, winner), wl2 = __shfl(l2, winner);
+        if (seg) {
+            ovx = wvx; ovy = wvy; ol2 = wl2;
+            still = false;
+        } else if (still) {
+            base += (uint32_t)H;
+        }
+        pending = __ballot(still);
+    }
+    if (need) {
+        const double rl = 1.0 / __builtin_sqrt(ol2);
+        rx = ovx * rl;
+        ry = ovy * rl;
     }
 }
 

@@ -282,6 +282,7 @@ int32_t rt2d_scene_create(rt_ctx *ctx, const rt2d_scene_desc *d, rt2d_scene **ou
     if (no && !d->materials) return fail(RT_E_INVALID, "null materials");
     if (nsp && !d->spectra) return fail(RT_E_INVALID, "null spectra");
     const int P = nc + ns;
+    const int ncp = nc + (nc & 1); // device-side circle count, padded to even for the packed f32 filter
     std::vector<char> seen((size_t)std::max(P, 1), 0);
     auto check_pid = [&](int pid) {
         if (pid < 0 || pid >= P || seen[(size_t)pid]) return false;
@@ -343,12 +344,12 @@ int32_t rt2d_scene_create(rt_ctx *ctx, const rt2d_scene_desc *d, rt2d_scene **ou
 
     Carver sz{ nullptr };
     auto layout = [&](Carver &c, rt2d::SceneDev &S, std::vector<char> *host) {
-        rt2d::Circle32 *c32 = c.take<rt2d::Circle32>(nc);
+        float *c32x = c.take<float>(ncp), *c32y = c.take<float>(ncp), *c32r = c.take<float>(ncp);
         double *iort = c.take<double>((size_t)nior * RT_NBINS), *inv_iort = c.take<double>((size_t)nior * RT_NBINS);
-        double *ccx = c.take<double>(nc), *ccy = c.take<double>(nc), *cr2 = c.take<double>(nc);
+        double *ccx = c.take<double>(ncp), *ccy = c.take<double>(ncp), *cr2 = c.take<double>(ncp);
         double *sax = c.take<double>(ns), *say = c.take<double>(ns), *ssx = c.take<double>(ns), *ssy = c.take<double>(ns);
         double *snx = c.take<double>(ns), *sny = c.take<double>(ns);
-        int32_t *cobj = c.take<int32_t>(nc), *cpid = c.take<int32_t>(nc), *sobj = c.take<int32_t>(ns), *spid = c.take<int32_t>(ns);
+        int32_t *cobj = c.take<int32_t>(ncp), *cpid = c.take<int32_t>(ncp), *sobj = c.take<int32_t>(ns), *spid = c.take<int32_t>(ns);
         rt2d::MatDev *mats = c.take<rt2d::MatDev>(no);
         float *spectra = c.take<float>((size_t)nsp * RT_NBINS);
         if (host) {
@@ -362,12 +363,16 @@ int32_t rt2d_scene_create(rt_ctx *ctx, const rt2d_scene_desc *d, rt2d_scene **ou
                 H(cr2)[k] = r2;
                 H(cobj)[k] = d->circle_obj[i];
                 H(cpid)[k] = d->circle_pid[i];
-                rt2d::Circle32 c3{};
-                c3.cx = (float)d->circle_cx[i];
-                c3.cy = (float)d->circle_cy[i];
                 const double q = 1.0 / (1.0 - 0x1.0p-17);
-                c3.r2q = std::nextafterf((float)((r2 * (1.0 + 0x1.0p-22) + 3.0e6 * delta * delta) * q), INFINITY);
-                H(c32)[k] = c3;
+                H(c32x)[k] = (float)d->circle_cx[i];
+                H(c32y)[k] = (float)d->circle_cy[i];
+                H(c32r)[k] = std::nextafterf((float)((r2 * (1.0 + 0x1.0p-22) + 3.0e6 * delta * delta) * q), INFINITY);
+            }
+            if (ncp > nc) {
+                // padding circle: the filter always drops it (g = -inf) and the exact test can never accept a NaN centre
+                H(c32x)[nc] = 0.0f; H(c32y)[nc] = 0.0f; H(c32r)[nc] = -INFINITY;
+                H(ccx)[nc] = NAN; H(ccy)[nc] = NAN; H(cr2)[nc] = 0.0;
+                H(cobj)[nc] = 0; H(cpid)[nc] = 0x7fffffff;
             }
             for (int k = 0; k < nior; ++k)
                 for (int b = 0; b < RT_NBINS; ++b) {
@@ -406,9 +411,8 @@ int32_t rt2d_scene_create(rt_ctx *ctx, const rt2d_scene_desc *d, rt2d_scene **ou
             }
             if (nsp) memcpy(H(spectra), d->spectra, sizeof(float) * (size_t)nsp * RT_NBINS);
         }
-        S.n_circ = nc; S.n_seg = ns; S.n_obj = no; S.pad_ = 0;
-        S.c32 = c32;
-        S.lds_c32 = nullptr;
+        S.n_circ = ncp; S.n_seg = ns; S.n_obj = no; S.pad_ = 0;
+        S.c32x = c32x; S.c32y = c32y; S.c32r = c32r;
         S.pad2_ = 0.0f;
         S.filt_eb = std::nextafterf((float)(0x1.0p-19 * cmax), INFINITY);
         S.filt_cmax = cmax;
@@ -492,8 +496,8 @@ int32_t launch_render2d(rt_ctx *ctx, const rt2d_scene *scene, const rt2d_render_
 #ifdef RT_PROF
     {
         static unsigned long long *d_prof = nullptr;
-        if (!d_prof) { HIP_TRY(hipMalloc((void **)&d_prof, 8 * sizeof(unsigned long long))); }
-        HIP_TRY(hipMemsetAsync(d_prof, 0, 8 * sizeof(unsigned long long), ctx->stream));
+        if (!d_prof) { HIP_TRY(hipMalloc((void **)&d_prof, 12 * sizeof(unsigned long long))); }
+        HIP_TRY(hipMemsetAsync(d_prof, 0, 12 * sizeof(unsigned long long), ctx->stream));
         A.prof_out = d_prof;
     }
 #endif
@@ -512,12 +516,13 @@ int32_t launch_render2d(rt_ctx *ctx, const rt2d_scene *scene, const rt2d_render_
     ctx->launches += 1;
 #ifdef RT_PROF
     {
-        unsigned long long h[8];
+        unsigned long long h[12];
         HIP_TRY(hipStreamSynchronize(ctx->stream));
         HIP_TRY(hipMemcpy(h, A.prof_out, sizeof h, hipMemcpyDeviceToHost));
-        const double tot = (double)(h[0] + h[1] + h[2] + h[3] + h[4]);
-        fprintf(stderr, "[rt_prof] regen %.3f phase1 %.3f phase2 %.3f shade %.3f loop %.3f | wave_steps %llu lanes/step %.2f cycles/step %.0f\n",
-                h[0] / tot, h[1] / tot, h[2] / tot, h[3] / tot, h[4] / tot, h[5], (double)h[6] / (double)h[5], tot / (double)h[5]);
+        const double tot = (double)(h[0] + h[1] + h[2] + h[3] + h[4] + h[7] + h[8] + h[9] + h[10]);
+        fprintf(stderr, "[rt_prof] regen %.3f phase1 %.3f phase2 %.3f classify %.3f normal %.3f bend %.3f diffuse %.3f tail %.3f loop %.3f | wave_steps %llu lanes/step %.2f cycles/step %.0f\n",
+                h[0] / tot, h[1] / tot, h[2] / tot, h[7] / tot, h[8] / tot, h[9] / tot, h[10] / tot, h[3] / tot, h[4] / tot, h[5],
+                (double)h[6] / (double)h[5], tot / (double)h[5]);
     }
 #endif
     const int64_t npx = list_mode ? n_list : (int64_t)p->width * p->height;

@@ -35,21 +35,12 @@ struct Render2dArgs {
 
 // ReverseRenderer::compute_pixel for every pixel of a tile
 // (2d/src/librt2d_reverse.rs:80-110), fused with trace_ray (:112-262).
-__global__ __launch_bounds__(BLOCK) void render2d_kernel(const Render2dArgs A)
+__global__ __launch_bounds__(BLOCK, 6) void render2d_kernel(const Render2dArgs A)
 {
     __shared__ float acc[TILE_PIXELS * NBINS];
     __shared__ int next_item;
     const int tid = threadIdx.x;
     const int tile = blockIdx.x;
-#if RT_PRIM_SRC == 2
-    __shared__ rt2d::Circle32 lds_c32[1024];
-    for (int i = tid; i < A.S.n_circ && i < 1024; i += BLOCK) lds_c32[i] = A.S.c32[i];
-    rt2d::SceneDev SS = A.S;
-    SS.lds_c32 = lds_c32;
-#define RT_SCENE SS
-#else
-#define RT_SCENE A.S
-#endif
     for (int i = tid; i < TILE_PIXELS * NBINS; i += BLOCK) acc[i] = 0.0f;
     if (tid == 0) next_item = 0;
     __syncthreads();
@@ -121,14 +112,18 @@ __global__ __launch_bounds__(BLOCK) void render2d_kernel(const Render2dArgs A)
         prof.t[5] += 1;
         prof.t[6] += (unsigned long long)__popcll(__ballot(run));
 #endif
-        const rt2d::Hit h = rt2d::nearest_hit(RT_SCENE, p.ox, p.oy, p.dx, p.dy, run, prof);
+        const rt2d::Hit h = rt2d::nearest_hit(A.S, p.ox, p.oy, p.dx, p.dy, run, prof);
+        float value = 0.0f;
+        double dnx = 0.0, dny = 0.0;
+        rt2d::ShadeResult r = rt2d::SHADE_DONE;
+        const uint32_t bounce_idx = (uint32_t)(A.recursion_limit - p.depth_left);
+        if (run) {
+            ++nrays;
+            r = rt2d::shade(A.S, p, h, value, dnx, dny, prof);
+        }
+        rt2d::rand_hemisphere_wave(run && r == rt2d::SHADE_DIFFUSE, dnx, dny, p.c0, p.c1, p.c2, bounce_idx, A.k0, A.k1, p.dx,
+                                   p.dy);
         if (alive) {
-            float value = 0.0f;
-            rt2d::ShadeResult r = rt2d::SHADE_DONE;
-            if (run) {
-                ++nrays;
-                r = rt2d::shade(A.S, p, h, A.recursion_limit, A.k0, A.k1, value);
-            }
             if (r == rt2d::SHADE_DONE) {
                 if (value != 0.0f) {
                     // per-sample term of `spectrum_spp / lambda_samples * 95` (librt2d_reverse.rs:104-105)
@@ -145,7 +140,7 @@ __global__ __launch_bounds__(BLOCK) void render2d_kernel(const Render2dArgs A)
     }
 #ifdef RT_PROF
     if ((tid & 63) == 0 && A.prof_out)
-        for (int i = 0; i < 8; ++i) atomicAdd(A.prof_out + i, prof.t[i]);
+        for (int i = 0; i < 12; ++i) atomicAdd(A.prof_out + i, prof.t[i]);
 #endif
 
     // rays traced by this wave -> one global atomic
@@ -197,17 +192,22 @@ __global__ __launch_bounds__(BLOCK) void trace_batch2d_kernel(const rt2d::SceneD
         const bool run = alive && p.depth_left > 0;
         Prof prof{};
         const rt2d::Hit h = rt2d::nearest_hit(S, p.ox, p.oy, p.dx, p.dy, run, prof);
+        float value = 0.0f;
+        double dnx = 0.0, dny = 0.0;
+        rt2d::ShadeResult r = rt2d::SHADE_DONE;
+        const uint32_t bounce_idx = (uint32_t)(depth - p.depth_left);
+        if (run) {
+            if (nb == 0 && h.slot >= 0) { fp = h.pid; ft = h.t; }
+            ++nb;
+            r = rt2d::shade(S, p, h, value, dnx, dny, prof);
+        }
+        rt2d::rand_hemisphere_wave(run && r == rt2d::SHADE_DIFFUSE, dnx, dny, p.c0, p.c1, p.c2, bounce_idx, k0, k1, p.dx, p.dy);
         if (alive) {
             if (!run) {
                 alive = false;
-            } else {
-                if (nb == 0 && h.slot >= 0) { fp = h.pid; ft = h.t; }
-                ++nb;
-                float value;
-                if (rt2d::shade(S, p, h, depth, k0, k1, value) == rt2d::SHADE_DONE) {
-                    out = p.thr * value;
-                    alive = false;
-                }
+            } else if (r == rt2d::SHADE_DONE) {
+                out = p.thr * value;
+                alive = false;
             }
         }
     }
