@@ -1,0 +1,59 @@
+// Front-end with the parameters of the reference's batch renderer (2d/src/bin/2d_reverse.rs:15-58):
+// 800x600, spp 500, recursion limit 10, 2 lambda samples, frames of sample_world(t), Reinhard{1.} PNGs.
+// Usage: rt2d_reverse [frames=1] [spp=500] [world=sample_world] [width=800] [out_prefix=out_]
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+
+#include "../raytracer_amd/host/png.hpp"
+#include "../raytracer_amd/host/worlds.hpp"
+
+using namespace rt2d_host;
+
+int main(int argc, char **argv)
+{
+    const int frames = argc > 1 ? atoi(argv[1]) : 1;
+    const size_t spp = argc > 2 ? (size_t)atoi(argv[2]) : 500;
+    const std::string world_name = argc > 3 ? argv[3] : "sample_world";
+    const int width = argc > 4 ? atoi(argv[4]) : 800;
+    const std::string prefix = argc > 5 ? argv[5] : "out_";
+    const int height = width * 3 / 4;
+
+    ReverseRenderParams params;
+    params.width = width;
+    params.height = height;
+    params.spp = spp;
+    params.recursion_limit = 10;
+    params.lambda_samples = 2;
+    params.px_to_world = 800.0 / width;
+    const Camera camera{ DVec2(800.0, 600.0) / 2.0, DVec2(800.0, 600.0) / 2.0 };
+    try {
+        ReverseRenderer renderer(params);
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int idx = 0; idx < frames; ++idx) {
+            printf("%d/%d\n", idx, frames - 1);
+            const double t = (double)idx / (double)(frames > 1 ? frames : 60);
+            const World world = worlds::by_name(world_name, camera, t, (uint64_t)idx, 1);
+            const RawImage raw = renderer.global_render(world, params);
+            std::vector<float> rgb((size_t)width * height * 3);
+            for (size_t i = 0; i < raw.data.size(); ++i) {
+                rgb[3 * i] = raw.data[i].value.x; rgb[3 * i + 1] = raw.data[i].value.y; rgb[3 * i + 2] = raw.data[i].value.z;
+            }
+            std::vector<uint8_t> rgba((size_t)width * height * 4);
+            if (rt_tonemap_reinhard(renderer.context(), rgb.data(), (int64_t)width * height, 1.0f, 255, rgba.data()) != RT_OK)
+                throw RtError(rt_last_error());
+            char name[256];
+            snprintf(name, sizeof name, "%s%04d.png", prefix.c_str(), idx);
+            if (!rt_png::write_rgba8(name, rgba.data(), width, height)) throw RtError(std::string("cannot write ") + name);
+        }
+        const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        rt_stats st{};
+        rt_ctx_get_stats(renderer.context(), &st);
+        printf("elapsed = %.3f s, %.1f Mrays/s in the trace kernel\n", s, (double)st.rays / st.kernel_ms / 1e3);
+    } catch (const std::exception &e) {
+        fprintf(stderr, "error: %s\n", e.what());
+        return 1;
+    }
+    return 0;
+}

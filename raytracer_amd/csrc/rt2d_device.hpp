@@ -186,6 +186,14 @@ RT_DEV Hit nearest_hit(const SceneDev &S, double ox, double oy, double dx, doubl
         uint64_t m0 = ((uint64_t)m[0] << 32) | m[1], m1 = ((uint64_t)m[2] << 32) | m[3];
         uint64_t m2 = ((uint64_t)m[4] << 32) | m[5], m3 = ((uint64_t)m[6] << 32) | m[7];
         if (!active) { m0 = m1 = m2 = m3 = 0; }
+#ifdef RT_PROF
+        {
+            int cnt = __popcll(m0) + __popcll(m1) + __popcll(m2) + __popcll(m3), mx = cnt;
+            for (int off = 32; off > 0; off >>= 1) { cnt += __shfl_xor(cnt, off); mx = max(mx, __shfl_xor(mx, off)); }
+            prof.t[10] += (unsigned long long)cnt;
+            prof.t[11] += (unsigned long long)mx;
+        }
+#endif
         RT_STAMP(prof, 1);
         while ((m0 | m1 | m2 | m3) != 0) {
             const int w = m0 ? 0 : m1 ? 1 : m2 ? 2 : 3;

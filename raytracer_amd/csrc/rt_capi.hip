@@ -496,8 +496,8 @@ int32_t launch_render2d(rt_ctx *ctx, const rt2d_scene *scene, const rt2d_render_
 #ifdef RT_PROF
     {
         static unsigned long long *d_prof = nullptr;
-        if (!d_prof) { HIP_TRY(hipMalloc((void **)&d_prof, 12 * sizeof(unsigned long long))); }
-        HIP_TRY(hipMemsetAsync(d_prof, 0, 12 * sizeof(unsigned long long), ctx->stream));
+        if (!d_prof) { HIP_TRY(hipMalloc((void **)&d_prof, 16 * sizeof(unsigned long long))); }
+        HIP_TRY(hipMemsetAsync(d_prof, 0, 16 * sizeof(unsigned long long), ctx->stream));
         A.prof_out = d_prof;
     }
 #endif
@@ -516,12 +516,14 @@ int32_t launch_render2d(rt_ctx *ctx, const rt2d_scene *scene, const rt2d_render_
     ctx->launches += 1;
 #ifdef RT_PROF
     {
-        unsigned long long h[12];
+        unsigned long long h[16];
         HIP_TRY(hipStreamSynchronize(ctx->stream));
         HIP_TRY(hipMemcpy(h, A.prof_out, sizeof h, hipMemcpyDeviceToHost));
-        const double tot = (double)(h[0] + h[1] + h[2] + h[3] + h[4] + h[7] + h[8] + h[9] + h[10]);
-        fprintf(stderr, "[rt_prof] regen %.3f phase1 %.3f phase2 %.3f classify %.3f normal %.3f bend %.3f diffuse %.3f tail %.3f loop %.3f | wave_steps %llu lanes/step %.2f cycles/step %.0f\n",
-                h[0] / tot, h[1] / tot, h[2] / tot, h[7] / tot, h[8] / tot, h[9] / tot, h[10] / tot, h[3] / tot, h[4] / tot, h[5],
+        const double tot = (double)(h[0] + h[1] + h[2] + h[3] + h[4] + h[7] + h[8] + h[9] + h[12] + h[13]);
+        fprintf(stderr, "[rt_prof] candidates per wave-step %.1f, phase-2 iterations (max over lanes) %.2f\n", (double)h[10] / (double)h[5],
+                (double)h[11] / (double)h[5]);
+        fprintf(stderr, "[rt_prof] regen %.3f phase1 %.3f phase2 %.3f classify %.3f normal %.3f bend %.3f shade-rest %.3f hemisphere %.3f tail %.3f loop %.3f | wave_steps %llu lanes/step %.2f cycles/step %.0f\n",
+                h[0] / tot, h[1] / tot, h[2] / tot, h[7] / tot, h[8] / tot, h[9] / tot, h[12] / tot, h[13] / tot, h[3] / tot, h[4] / tot, h[5],
                 (double)h[6] / (double)h[5], tot / (double)h[5]);
     }
 #endif

@@ -121,8 +121,10 @@ __global__ __launch_bounds__(BLOCK, 6) void render2d_kernel(const Render2dArgs A
             ++nrays;
             r = rt2d::shade(A.S, p, h, value, dnx, dny, prof);
         }
+        RT_STAMP(prof, 12);
         rt2d::rand_hemisphere_wave(run && r == rt2d::SHADE_DIFFUSE, dnx, dny, p.c0, p.c1, p.c2, bounce_idx, A.k0, A.k1, p.dx,
                                    p.dy);
+        RT_STAMP(prof, 13);
         if (alive) {
             if (r == rt2d::SHADE_DONE) {
                 if (value != 0.0f) {
@@ -140,7 +142,7 @@ __global__ __launch_bounds__(BLOCK, 6) void render2d_kernel(const Render2dArgs A
     }
 #ifdef RT_PROF
     if ((tid & 63) == 0 && A.prof_out)
-        for (int i = 0; i < 12; ++i) atomicAdd(A.prof_out + i, prof.t[i]);
+        for (int i = 0; i < 16; ++i) atomicAdd(A.prof_out + i, prof.t[i]);
 #endif
 
     // rays traced by this wave -> one global atomic
