@@ -133,6 +133,7 @@ const char *rt_version(void);
 const char *rt_last_error(void);
 int32_t rt_device_count(int32_t *count);
 int32_t rt_ctx_create(int32_t device_id, rt_ctx **out);
+/* Fails with RT_E_INVALID, and leaves the context intact, while scenes created on it are still alive. */
 int32_t rt_ctx_destroy(rt_ctx *ctx);
 /* A new context enqueues its work on a non-blocking stream of its own.
  * rt_ctx_set_stream switches it to the caller's `hip_stream` (a hipStream_t; NULL is

@@ -1,6 +1,7 @@
 """Object wrappers over the C ABI (see _ffi.py).  Names follow the reference:
 World, ReverseRenderParams fields, global_render / compute_pixel / trace_ray."""
 import ctypes as C
+import weakref
 
 import numpy as np
 
@@ -111,6 +112,7 @@ class Context:
 
     def __init__(self, device=0, stream=None):
         self._ctx = C.c_void_p()
+        self._scenes = weakref.WeakSet()  # closed with the context: the library refuses to drop a context that owns scenes
         check(_ffi.lib().rt_ctx_create(int(device), C.byref(self._ctx)))
         if stream is not None:
             self.set_stream(stream)
@@ -142,7 +144,9 @@ class Context:
 
     def close(self):
         if getattr(self, "_ctx", None):
-            _ffi.lib().rt_ctx_destroy(self._ctx)
+            for sc in list(self._scenes):
+                sc.close()
+            check(_ffi.lib().rt_ctx_destroy(self._ctx))
             self._ctx = None
 
     def __del__(self):
@@ -168,6 +172,7 @@ class Scene2D:
         self._world = world  # keeps the desc arrays alive during creation
         self._sc = C.c_void_p()
         check(_ffi.lib().rt2d_scene_create(ctx._ctx, C.byref(world.desc), C.byref(self._sc)))
+        ctx._scenes.add(self)
         self.n_prims = world.n_prims
 
     def global_render(self, p, want_spectrum=False):
@@ -245,6 +250,7 @@ class Scene3D:
         self.width, self.height = scene.desc.width, scene.desc.height
         self._sc = C.c_void_p()
         check(_ffi.lib().rt3d_scene_create(ctx._ctx, C.byref(scene.desc), C.byref(self._sc)))
+        ctx._scenes.add(self)
 
     def render(self, p):
         out = np.empty((self.height, self.width, 3), np.float32)

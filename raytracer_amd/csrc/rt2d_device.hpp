@@ -30,10 +30,12 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // reference recomputes in every hit test (rt_common.rs:83, :244).
 struct SceneDev {
     int32_t n_circ, n_seg, n_obj, pad_; // n_circ is even: an odd circle count is padded with a circle nothing can hit
-    // circles as the f32 filter sees them (see filter_word): centre rounded to f32, padded squared radius
-    const float *c32x, *c32y, *c32r;
-    float filt_eb, pad2_; // bound on the f32 error of d.(o-c)
-    double filt_cmax;      // the f32 filter is proven for |origin|_inf <= filt_cmax and |dir|^2 <= 2
+    // circles as the f32 filter sees them (see filter_word), relative to the filter frame's centre
+    // (filt_mx, filt_my): c32x/c32y = centre - frame centre rounded to f32, c32e = r^2 (1 + 2^-21) - |c32|^2 rounded up
+    const float *c32x, *c32y, *c32e;
+    // filter frame, set per launch: the filter is proven for |origin - centre|_inf <= filt_B and |dir|^2 <= 1.001;
+    // filt_eb = 2^-20 filt_B bounds the f32 error of d.(o-c), filt_M = 200 * 2^-24 filt_B^2 pads the squared radius
+    double filt_mx, filt_my, filt_B, filt_eb, filt_M;
     const double *ior, *inv_ior; // [n_ior][95]: Ior::ior(lambda_i) and its reciprocal (rt_common.rs:442-450)
     const double *ccx, *ccy, *cr2;
     const double *sax, *say, *ssx, *ssy, *snx, *sny;
@@ -85,21 +87,27 @@ RT_DEV bool segment_t(double ox, double oy, double rx, double ry, double ax, dou
 //    scalar operands): a cheap test marks the lanes for which the primitive can
 //    still be a hit.  It decides with SIGN BITS only (no sqrt, division or
 //    compare) and it never drops a hit the reference would report:
-//    circle, in f32 with fused ops: with oc = o - c, bp = d.oc, l2 = |oc|^2 the
-//      reference needs D = bp^2 - l2 + r^2 >= 0 (its delta / 4) and a positive
-//      root, and has no positive root when bp >= 0 and l2 >= r^2.  Rounding o, c, d
-//      to f32 moves each component of oc by at most DELTA = 2^-22 * cmax * 1.001
-//      (|o|, |c| <= cmax per component) and, with |d|^2 <= 2,
-//        |bp_f - bp| <= 2.002 DELTA + 2.53e-7 |oc|  (< eb = 2^-19 cmax),
-//        |bp_f^2 - bp^2| + |l2_f - l2| + roundings <= 8.52 DELTA |oc| + 10.1 DELTA^2 + 1.1e-6 l2 + 1.2e-7 r^2.
-//      The test computes g = q bp_f^2 + q r2e - l2_f, q = 1 / (1 - 2^-17), i.e.
-//      q times (bp_f^2 + r2e - (1 - 2^-17) l2_f), with r2e = r^2 (1 + 2^-22) +
-//      3.0e6 DELTA^2 and q r2e rounded up (the factor q rides on the direction,
-//      pre-scaled by sqrt(q), which adds 2.4e-7 l2 to the bound); since
-//      8.52 DELTA |oc| <= 2.88e6 DELTA^2 + 6.3e-6 l2, g >= 0 whenever D >= 0.  A
-//      circle is also dropped when sqrt(q) bp_f > eb (so bp > 0) and q r2e <= l2_f
-//      (so l2 > r^2): both of the reference's roots are then <= 0.
-//      Lanes whose origin or direction lies outside those bounds mark every slot.
+//    circle, in f32 with fused ops, in coordinates relative to the frame centre m:
+//      u = o - m, v = c - m (|u_i|, |v_i| <= B), bp = d.(u - v), l2 = |u - v|^2.  The
+//      reference needs D = bp^2 - l2 + r^2 >= 0 (its delta / 4) and a positive root,
+//      and has no positive root when bp > 0 and l2 > r^2.  Both are evaluated in
+//      expanded form so that a circle costs six packed operations:
+//        fbn   = (d.u - eb) - dy vy - dx vx            ~ bp - eb
+//        inner = (e - (|u|^2 - M)) + 2 uy vy + 2 ux vx ~ r^2 + pad - l2,  e = r^2 (1 + 2^-21) - |v|^2
+//        g     = fbn^2 + inner                         ~ D + pad
+//      with u, v, d rounded to f32 (eps = 2^-24, |d_i| <= 1.0005):
+//        |fbn - (bp - eb)| <= 10.7 eps B  (roundings of d.u - eb, the two fused steps, and of
+//          the inputs), so with eb = 16 eps B: fbn >= 0 implies bp >= 5.3 eps B > 0, and
+//          |fbn - bp| <= 26.7 eps B;
+//        |inner - (r^2 + pad - l2)| <= eps (3 (r^2 + pad) + 36.1 B^2)  (rounding |u|^2 - M, three
+//          fused steps of magnitude <= r^2 + pad + 8 B^2, and 16.02 eps B^2 from rounding u, v);
+//        fbn^2 >= bp^2 - 2 |bp| 26.7 eps B >= bp^2 - 151.3 eps B^2  (|bp| <= 2.832 B).
+//      Hence g >= D + pad - eps (3 (r^2 + pad) + 187.4 B^2) and pad = 2^-21 r^2 + 200 eps B^2 makes
+//      g >= 0 whenever D >= 0 (the final rounding keeps the sign); inner < 0 implies
+//      l2 - r^2 > 5 eps r^2 + 163 eps B^2 > 0.  Those slacks exceed the f64 rounding of the
+//      reference's own delta and roots (<= 2^-50 (B^2 + r^2)) by many orders of magnitude.
+//      A circle is kept iff g >= 0 and not (fbn >= 0 and inner < 0).
+//      Lanes whose origin or direction lies outside the frame mark every slot.
 //    segment, exact f64: the reference's own three cross products; t = tn/den >= 0
 //      and 0 <= u = un/den <= 1 fail for sure when tn (or un) is not tiny
 //      (|.| >= 2^-900) and differs in sign from den, or when |un| exceeds |den| by
@@ -109,30 +117,49 @@ RT_DEV bool segment_t(double ox, double oy, double rx, double ry, double ax, dou
 //    the reference's operation order, then (total_cmp key, pid) lexicographic
 //    minimum = "first minimum in scan order" (librt2d_reverse.rs:139).
 // Inactive lanes run phase 1 with the wave and skip phase 2.
-RT_DEV uint32_t filter_word(const SceneDev &S, int lo, int hi, double ox, double oy, double dx, double dy, float oxf,
-                            float oyf, float dxq, float dyq, uint32_t force)
+// Per-ray operands of the circle filter, each duplicated into both halves of a packed register.
+struct FilterRay {
+    f32x2 ndx, ndy; // -d
+    f32x2 ke;       // d.u - eb
+    f32x2 ax, ay;   // 2 u
+    f32x2 o2m;      // |u|^2 - M
+};
+
+RT_DEV FilterRay filter_ray(const SceneDev &S, double ox, double oy, double dx, double dy, bool &in_range)
+{
+    const double ux = ox - S.filt_mx, uy = oy - S.filt_my;
+    in_range = __builtin_fabs(ux) <= S.filt_B && __builtin_fabs(uy) <= S.filt_B && dx * dx + dy * dy <= 1.001;
+    const float uxf = (float)ux, uyf = (float)uy, dxf = (float)dx, dyf = (float)dy;
+    const float ke = (float)((dx * ux + dy * uy) - S.filt_eb);
+    const float o2m = (float)(((double)uxf * (double)uxf + (double)uyf * (double)uyf) - S.filt_M);
+    FilterRay f;
+    f.ndx = f32x2{ -dxf, -dxf };
+    f.ndy = f32x2{ -dyf, -dyf };
+    f.ke = f32x2{ ke, ke };
+    f.ax = f32x2{ 2.0f * uxf, 2.0f * uxf };
+    f.ay = f32x2{ 2.0f * uyf, 2.0f * uyf };
+    f.o2m = f32x2{ o2m, o2m };
+    return f;
+}
+
+RT_DEV uint32_t filter_word(const SceneDev &S, int lo, int hi, double ox, double oy, double dx, double dy, const FilterRay &f,
+                            uint32_t force)
 {
     uint32_t acc = 0;
     const int c_end = hi < S.n_circ ? hi : S.n_circ;
-    // two circles per packed f32 instruction (v_pk_add/mul/fma_f32): the circle count is padded to even
+    // two circles per packed f32 instruction (v_pk_add/fma_f32): the circle count is padded to even
     // and word boundaries are even, so a pair never straddles a word
-    float ebv;
-    asm("v_mov_b32 %0, %1" : "=v"(ebv) : "s"(S.filt_eb)); // in a VGPR: a scalar operand costs a VALU op ~2 extra cycles
-    const f32x2 ox2 = { oxf, oxf }, oy2 = { oyf, oyf }, dx2 = { dxq, dxq }, dy2 = { dyq, dyq }, eb2 = { ebv, ebv };
 #pragma unroll 4
     for (int s = lo; s < c_end; s += 2) {
-        const f32x2 cx = *reinterpret_cast<const f32x2 *>(S.c32x + s);
-        const f32x2 cy = *reinterpret_cast<const f32x2 *>(S.c32y + s);
-        const f32x2 r2q = *reinterpret_cast<const f32x2 *>(S.c32r + s);
-        const f32x2 ocx = ox2 - cx, ocy = oy2 - cy;
-        const f32x2 bq = __builtin_elementwise_fma(dx2, ocx, dy2 * ocy); // d.oc * sqrt(q)
-        const f32x2 l2 = __builtin_elementwise_fma(ocx, ocx, ocy * ocy);
-        const f32x2 inner = r2q - l2;                                    // ~ (r^2 - |oc|^2 / q) q, padded upward
-        const f32x2 g = __builtin_elementwise_fma(bq, bq, inner);        // ~ q * discriminant / 4, padded upward
-        const f32x2 fb = eb2 - bq;                                       // sign set: surely moving away from the centre
-        // keep iff g >= 0 and not (moving away and origin surely outside)
-        const uint32_t keep0 = ~__float_as_uint(g.x) & (~__float_as_uint(fb.x) | ~__float_as_uint(inner.x));
-        const uint32_t keep1 = ~__float_as_uint(g.y) & (~__float_as_uint(fb.y) | ~__float_as_uint(inner.y));
+        const f32x2 vx = *reinterpret_cast<const f32x2 *>(S.c32x + s);
+        const f32x2 vy = *reinterpret_cast<const f32x2 *>(S.c32y + s);
+        const f32x2 e = *reinterpret_cast<const f32x2 *>(S.c32e + s);
+        const f32x2 fbn = __builtin_elementwise_fma(f.ndx, vx, __builtin_elementwise_fma(f.ndy, vy, f.ke));
+        const f32x2 inner = __builtin_elementwise_fma(f.ax, vx, __builtin_elementwise_fma(f.ay, vy, e - f.o2m));
+        const f32x2 g = __builtin_elementwise_fma(fbn, fbn, inner);
+        // keep iff g >= 0 and not (surely moving away and origin surely outside)
+        const uint32_t keep0 = ~__float_as_uint(g.x) & (__float_as_uint(fbn.x) | ~__float_as_uint(inner.x));
+        const uint32_t keep1 = ~__float_as_uint(g.y) & (__float_as_uint(fbn.y) | ~__float_as_uint(inner.y));
         acc = __builtin_amdgcn_alignbit(acc, keep0, 31);
         acc = __builtin_amdgcn_alignbit(acc, keep1, 31);
     }
@@ -167,11 +194,9 @@ RT_DEV Hit nearest_hit(const SceneDev &S, double ox, double oy, double dx, doubl
     best.pid = 0x7fffffff;
     int64_t best_key = 0x7fffffffffffffffLL;
     const int P = S.n_circ + S.n_seg;
-    // q = 1 / (1 - 2^-17); the direction is pre-scaled by sqrt(q) so that (d.oc)^2 arrives multiplied by q
-    constexpr double SQRT_Q = 1.0000038147190937;
-    const float oxf = (float)ox, oyf = (float)oy, dxq = (float)(dx * SQRT_Q), dyq = (float)(dy * SQRT_Q);
-    // outside the range the f32 filter is proven for: every slot becomes a candidate (exact tests decide)
-    const bool in_range = __builtin_fabs(ox) <= S.filt_cmax && __builtin_fabs(oy) <= S.filt_cmax && dx * dx + dy * dy <= 2.0;
+    // outside the frame the f32 filter is proven for, every slot becomes a candidate (exact tests decide)
+    bool in_range;
+    const FilterRay fr = filter_ray(S, ox, oy, dx, dy, in_range);
     const uint32_t force = in_range ? 0u : 0xFFFFFFFFu;
     for (int base = 0; base < P; base += 256) {
         uint32_t m[8];
@@ -181,7 +206,7 @@ RT_DEV Hit nearest_hit(const SceneDev &S, double ox, double oy, double dx, doubl
             const int hi = (lo + 32 < P) ? lo + 32 : P;
             // bits below the word's last slot are shifted-in zeros; `force` may set them, so mask to the valid slots
             const uint32_t valid = 0xFFFFFFFFu << (32 - ((lo < P) ? hi - lo : 32));
-            m[w] = (lo < P) ? (filter_word(S, lo, hi, ox, oy, dx, dy, oxf, oyf, dxq, dyq, force) & valid) : 0u;
+            m[w] = (lo < P) ? (filter_word(S, lo, hi, ox, oy, dx, dy, fr, force) & valid) : 0u;
         }
         uint64_t m0 = ((uint64_t)m[0] << 32) | m[1], m1 = ((uint64_t)m[2] << 32) | m[3];
         uint64_t m2 = ((uint64_t)m[4] << 32) | m[5], m3 = ((uint64_t)m[6] << 32) | m[7];

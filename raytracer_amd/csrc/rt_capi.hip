@@ -76,6 +76,7 @@ struct rt_ctx {
     // grow-only device workspace for the host-pointer entry points
     void *ws = nullptr;
     size_t ws_bytes = 0;
+    int live_scenes = 0; // scenes created on this context and not yet destroyed
 };
 
 struct rt2d_scene {
@@ -83,6 +84,7 @@ struct rt2d_scene {
     void *blob = nullptr;
     rt2d::SceneDev dev{};
     int n_prims = 0;
+    double lo[2] = { 0.0, 0.0 }, hi[2] = { 0.0, 0.0 }; // bounding box of every primitive (circles with their radius)
 };
 
 struct rt3d_scene {
@@ -204,6 +206,7 @@ int32_t rt_ctx_create(int32_t device_id, rt_ctx **out)
 int32_t rt_ctx_destroy(rt_ctx *ctx)
 {
     if (!ctx) return RT_OK;
+    if (ctx->live_scenes != 0) return fail(RT_E_INVALID, "context still owns %d scene(s): destroy them first", ctx->live_scenes);
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     for (auto &ev : ctx->pending) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
@@ -333,18 +336,23 @@ int32_t rt2d_scene_create(rt_ctx *ctx, const rt2d_scene_desc *d, rt2d_scene **ou
     }
     const int nior = (int)iors.size();
 
-    // bounds of the f32 circle filter (see rt2d_device.hpp): origins up to twice the scene's extent
-    double abs_max = 1.0;
-    for (int i = 0; i < nc; ++i) abs_max = std::max(abs_max, std::max(std::fabs(d->circle_cx[i]), std::fabs(d->circle_cy[i])));
-    for (int i = 0; i < ns; ++i)
-        abs_max = std::max(abs_max, std::max(std::max(std::fabs(d->seg_ax[i]), std::fabs(d->seg_ay[i])),
-                                             std::max(std::fabs(d->seg_bx[i]), std::fabs(d->seg_by[i]))));
-    const double cmax = 2.0 * abs_max;
-    const double delta = 0x1.0p-22 * cmax * 1.001;
+    // bounding box of the primitives; its centre is the origin of the f32 circle filter's frame (see rt2d_device.hpp)
+    double blo[2] = { INFINITY, INFINITY }, bhi[2] = { -INFINITY, -INFINITY };
+    auto grow = [&](double x, double y) {
+        blo[0] = std::min(blo[0], x); bhi[0] = std::max(bhi[0], x);
+        blo[1] = std::min(blo[1], y); bhi[1] = std::max(bhi[1], y);
+    };
+    for (int i = 0; i < nc; ++i) {
+        grow(d->circle_cx[i] - d->circle_r[i], d->circle_cy[i] - d->circle_r[i]);
+        grow(d->circle_cx[i] + d->circle_r[i], d->circle_cy[i] + d->circle_r[i]);
+    }
+    for (int i = 0; i < ns; ++i) { grow(d->seg_ax[i], d->seg_ay[i]); grow(d->seg_bx[i], d->seg_by[i]); }
+    if (P == 0) { blo[0] = blo[1] = 0.0; bhi[0] = bhi[1] = 0.0; }
+    const double fmx = 0.5 * (blo[0] + bhi[0]), fmy = 0.5 * (blo[1] + bhi[1]);
 
     Carver sz{ nullptr };
     auto layout = [&](Carver &c, rt2d::SceneDev &S, std::vector<char> *host) {
-        float *c32x = c.take<float>(ncp), *c32y = c.take<float>(ncp), *c32r = c.take<float>(ncp);
+        float *c32x = c.take<float>(ncp), *c32y = c.take<float>(ncp), *c32e = c.take<float>(ncp);
         double *iort = c.take<double>((size_t)nior * RT_NBINS), *inv_iort = c.take<double>((size_t)nior * RT_NBINS);
         double *ccx = c.take<double>(ncp), *ccy = c.take<double>(ncp), *cr2 = c.take<double>(ncp);
         double *sax = c.take<double>(ns), *say = c.take<double>(ns), *ssx = c.take<double>(ns), *ssy = c.take<double>(ns);
@@ -363,14 +371,15 @@ int32_t rt2d_scene_create(rt_ctx *ctx, const rt2d_scene_desc *d, rt2d_scene **ou
                 H(cr2)[k] = r2;
                 H(cobj)[k] = d->circle_obj[i];
                 H(cpid)[k] = d->circle_pid[i];
-                const double q = 1.0 / (1.0 - 0x1.0p-17);
-                H(c32x)[k] = (float)d->circle_cx[i];
-                H(c32y)[k] = (float)d->circle_cy[i];
-                H(c32r)[k] = std::nextafterf((float)((r2 * (1.0 + 0x1.0p-22) + 3.0e6 * delta * delta) * q), INFINITY);
+                const float vx = (float)(d->circle_cx[i] - fmx), vy = (float)(d->circle_cy[i] - fmy);
+                H(c32x)[k] = vx;
+                H(c32y)[k] = vy;
+                H(c32e)[k] = std::nextafterf(
+                    (float)(r2 * (1.0 + 0x1.0p-21) - ((double)vx * (double)vx + (double)vy * (double)vy)), INFINITY);
             }
             if (ncp > nc) {
                 // padding circle: the filter always drops it (g = -inf) and the exact test can never accept a NaN centre
-                H(c32x)[nc] = 0.0f; H(c32y)[nc] = 0.0f; H(c32r)[nc] = -INFINITY;
+                H(c32x)[nc] = 0.0f; H(c32y)[nc] = 0.0f; H(c32e)[nc] = -INFINITY;
                 H(ccx)[nc] = NAN; H(ccy)[nc] = NAN; H(cr2)[nc] = 0.0;
                 H(cobj)[nc] = 0; H(cpid)[nc] = 0x7fffffff;
             }
@@ -412,10 +421,9 @@ int32_t rt2d_scene_create(rt_ctx *ctx, const rt2d_scene_desc *d, rt2d_scene **ou
             if (nsp) memcpy(H(spectra), d->spectra, sizeof(float) * (size_t)nsp * RT_NBINS);
         }
         S.n_circ = ncp; S.n_seg = ns; S.n_obj = no; S.pad_ = 0;
-        S.c32x = c32x; S.c32y = c32y; S.c32r = c32r;
-        S.pad2_ = 0.0f;
-        S.filt_eb = std::nextafterf((float)(0x1.0p-19 * cmax), INFINITY);
-        S.filt_cmax = cmax;
+        S.c32x = c32x; S.c32y = c32y; S.c32e = c32e;
+        S.filt_mx = fmx; S.filt_my = fmy;
+        S.filt_B = 0.0; S.filt_eb = 0.0; S.filt_M = 0.0; // set per launch by filter_frame
         S.ior = iort; S.inv_ior = inv_iort;
         S.ccx = ccx; S.ccy = ccy; S.cr2 = cr2;
         S.sax = sax; S.say = say; S.ssx = ssx; S.ssy = ssy; S.snx = snx; S.sny = sny;
@@ -430,6 +438,7 @@ int32_t rt2d_scene_create(rt_ctx *ctx, const rt2d_scene_desc *d, rt2d_scene **ou
     if (!sc) return fail(RT_E_OOM, "host allocation failed");
     sc->ctx = ctx;
     sc->n_prims = P;
+    sc->lo[0] = blo[0]; sc->lo[1] = blo[1]; sc->hi[0] = bhi[0]; sc->hi[1] = bhi[1];
     hipError_t e = hipMalloc(&sc->blob, bytes);
     if (e != hipSuccess) {
         delete sc;
@@ -444,6 +453,7 @@ int32_t rt2d_scene_create(rt_ctx *ctx, const rt2d_scene_desc *d, rt2d_scene **ou
         delete sc;
         return fail(RT_E_HIP, "scene upload: %s", hipGetErrorString(e));
     }
+    ctx->live_scenes += 1;
     *out = sc;
     return RT_OK;
 }
@@ -451,6 +461,7 @@ int32_t rt2d_scene_create(rt_ctx *ctx, const rt2d_scene_desc *d, rt2d_scene **ou
 int32_t rt2d_scene_destroy(rt2d_scene *scene)
 {
     if (!scene) return RT_OK;
+    scene->ctx->live_scenes -= 1;
     (void)hipSetDevice(scene->ctx->device);
     (void)hipStreamSynchronize(scene->ctx->stream);
     if (scene->blob) (void)hipFree(scene->blob);
@@ -477,11 +488,42 @@ int32_t check_params2d(const rt2d_render_params *p)
     return RT_OK;
 }
 
+// Scene operand of one launch: the circle filter's frame is sized to hold the scene's bounding box and the
+// box [lo, hi] of the launch's first ray origins (every later origin is a hit point, inside the scene's box).
+// The frame is capped at 4x the scene's own half extent: the filter's padding grows with the square of the
+// frame, and origins beyond it take the unfiltered path.
+rt2d::SceneDev filter_frame(const rt2d_scene *scene, const double lo[2], const double hi[2])
+{
+    rt2d::SceneDev S = scene->dev;
+    double half = 0.0, want = 0.0;
+    for (int a = 0; a < 2; ++a) {
+        const double m = a == 0 ? S.filt_mx : S.filt_my;
+        half = std::max(half, std::max(std::fabs(scene->lo[a] - m), std::fabs(scene->hi[a] - m)));
+        want = std::max(want, std::max(std::fabs(lo[a] - m), std::fabs(hi[a] - m)));
+    }
+    half = std::max(half, 0x1.0p-300);
+    const double B = std::min(std::max(half, want), 4.0 * half) * (1.0 + 0x1.0p-20);
+    S.filt_B = B;
+    S.filt_eb = 0x1.0p-20 * B;
+    S.filt_M = 200.0 * 0x1.0p-24 * B * B;
+    return S;
+}
+
 int32_t launch_render2d(rt_ctx *ctx, const rt2d_scene *scene, const rt2d_render_params *p, int list_mode, int64_t n_list,
-                        const int32_t *d_px, const int32_t *d_py, float *d_out)
+                        const int32_t *d_px, const int32_t *d_py, float *d_out, const double *lo_px = nullptr,
+                        const double *hi_px = nullptr)
 {
     rtk::Render2dArgs A{};
-    A.S = scene->dev;
+    {
+        // first origins: pixel centres +- half a pixel (generate, rt2d_device.hpp)
+        double lo[2] = { -0.5 * p->px_to_world, -0.5 * p->px_to_world };
+        double hi[2] = { ((double)p->width - 0.5) * p->px_to_world, ((double)p->height - 0.5) * p->px_to_world };
+        if (list_mode) {
+            lo[0] = (lo_px[0] - 0.5) * p->px_to_world; lo[1] = (lo_px[1] - 0.5) * p->px_to_world;
+            hi[0] = (hi_px[0] + 0.5) * p->px_to_world; hi[1] = (hi_px[1] + 0.5) * p->px_to_world;
+        }
+        A.S = filter_frame(scene, lo, hi);
+    }
     A.width = p->width; A.height = p->height; A.spp = p->spp; A.lambda_samples = p->lambda_samples;
     A.recursion_limit = p->recursion_limit; A.sample_offset = p->sample_offset;
     A.k0 = (uint32_t)p->seed; A.k1 = (uint32_t)(p->seed >> 32);
@@ -610,10 +652,13 @@ int32_t rt2d_compute_pixels(rt_ctx *ctx, const rt2d_scene *scene, const rt2d_ren
     if (n == 0) return RT_OK;
     if (!px || !py || !out_spectrum) return fail(RT_E_INVALID, "null argument");
     if (n > (1LL << 30)) return fail(RT_E_LIMIT, "more than 2^30 pixels");
+    double lo_px[2] = { INFINITY, INFINITY }, hi_px[2] = { -INFINITY, -INFINITY };
     for (int64_t k = 0; k < n; ++k) {
         const double lim = MAX_COORD / p->px_to_world;
         if (std::fabs((double)px[k]) > lim || std::fabs((double)py[k]) > lim)
             return fail(RT_E_INVALID, "pixel %lld maps outside |v| <= 2^40", (long long)k);
+        lo_px[0] = std::min(lo_px[0], (double)px[k]); hi_px[0] = std::max(hi_px[0], (double)px[k]);
+        lo_px[1] = std::min(lo_px[1], (double)py[k]); hi_px[1] = std::max(hi_px[1], (double)py[k]);
     }
     Carver c{ nullptr };
     c.take<int32_t>((size_t)n); c.take<int32_t>((size_t)n); c.take<float>((size_t)n * RT_NBINS);
@@ -624,7 +669,7 @@ int32_t rt2d_compute_pixels(rt_ctx *ctx, const rt2d_scene *scene, const rt2d_ren
     float *d_out = w.take<float>((size_t)n * RT_NBINS);
     HIP_TRY(hipMemcpyAsync(d_px, px, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipMemcpyAsync(d_py, py, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
-    if (int32_t rc = launch_render2d(ctx, scene, p, 1, n, d_px, d_py, d_out)) return rc;
+    if (int32_t rc = launch_render2d(ctx, scene, p, 1, n, d_px, d_py, d_out, lo_px, hi_px)) return rc;
     HIP_TRY(hipMemcpyAsync(out_spectrum, d_out, sizeof(float) * (size_t)n * RT_NBINS, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return RT_OK;
@@ -641,10 +686,13 @@ int32_t rt2d_trace_batch(rt_ctx *ctx, const rt2d_scene *scene, int64_t n, const 
     if (!ox || !oy || !dx || !dy || !lambda_idx || !radiance) return fail(RT_E_INVALID, "null argument");
     if (depth < 0 || depth > 4095) return fail(RT_E_LIMIT, "depth must be in 0..4095");
     if (n > (1LL << 31) * rtk::BLOCK) return fail(RT_E_LIMIT, "batch too large");
+    double lo_o[2] = { INFINITY, INFINITY }, hi_o[2] = { -INFINITY, -INFINITY };
     for (int64_t i = 0; i < n; ++i) {
         if (!finite_within(ox[i], MAX_COORD) || !finite_within(oy[i], MAX_COORD) || !finite_within(dx[i], MAX_DIR) ||
             !finite_within(dy[i], MAX_DIR))
             return fail(RT_E_INVALID, "ray %lld: origin must be finite with |v| <= 2^40, direction with |v| <= 2^20", (long long)i);
+        lo_o[0] = std::min(lo_o[0], ox[i]); hi_o[0] = std::max(hi_o[0], ox[i]);
+        lo_o[1] = std::min(lo_o[1], oy[i]); hi_o[1] = std::max(hi_o[1], oy[i]);
         if (lambda_idx[i] < 0 || lambda_idx[i] >= RT_NBINS) return fail(RT_E_INVALID, "ray %lld: lambda_idx out of 0..94", (long long)i);
     }
     Carver c{ nullptr };
@@ -668,7 +716,7 @@ int32_t rt2d_trace_batch(rt_ctx *ctx, const rt2d_scene *scene, int64_t n, const 
     if (int32_t rc = event_pair(ctx, &ev)) return rc;
     HIP_TRY(hipEventRecord(ev.first, ctx->stream));
     const unsigned blocks = (unsigned)((n + rtk::BLOCK - 1) / rtk::BLOCK);
-    hipLaunchKernelGGL(rtk::trace_batch2d_kernel, dim3(blocks), dim3(rtk::BLOCK), 0, ctx->stream, scene->dev, n, d_ox, d_oy, d_dx,
+    hipLaunchKernelGGL(rtk::trace_batch2d_kernel, dim3(blocks), dim3(rtk::BLOCK), 0, ctx->stream, filter_frame(scene, lo_o, hi_o), n, d_ox, d_oy, d_dx,
                        d_dy, d_li, depth, (uint32_t)seed, (uint32_t)(seed >> 32), d_rad, d_fp, d_ft, d_nb, ctx->d_rays);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(ev.second, ctx->stream));
@@ -854,6 +902,7 @@ int32_t rt3d_scene_create(rt_ctx *ctx, const rt3d_scene_desc *d, rt3d_scene **ou
         return fail(RT_E_HIP, "scene upload: %s", hipGetErrorString(e));
     }
     sc->dev = S;
+    ctx->live_scenes += 1;
     *out = sc;
     return RT_OK;
 }
@@ -861,6 +910,7 @@ int32_t rt3d_scene_create(rt_ctx *ctx, const rt3d_scene_desc *d, rt3d_scene **ou
 int32_t rt3d_scene_destroy(rt3d_scene *scene)
 {
     if (!scene) return RT_OK;
+    scene->ctx->live_scenes -= 1;
     (void)hipSetDevice(scene->ctx->device);
     (void)hipStreamSynchronize(scene->ctx->stream);
     if (scene->blob) (void)hipFree(scene->blob);

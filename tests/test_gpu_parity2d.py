@@ -109,3 +109,76 @@ def test_invalid_arguments_are_rejected(gpu_ctx):
         scene.trace_batch(one, one, one, one, np.full(4, 95, np.int32), depth=3)
     with pytest.raises(rt.RtError):
         scene.trace_batch(one, one, one, one, np.zeros(4, np.int32), depth=-1)
+
+
+def _grazing_rays(world, n, seed, span=(800.0, 600.0), spread=1.0):
+    """Rays aimed at the rim of circles (discriminant ~ 0) and rays leaving from circle rims (d.(o-c) ~ 0 or
+    origin on the boundary): the cases the conservative first-phase filter must never drop."""
+    a = world.arrays()
+    cx, cy, r = a["circle_cx"], a["circle_cy"], a["circle_r"]
+    rng = np.random.default_rng(seed)
+    k = rng.integers(0, len(cx), n)
+    eps = np.concatenate([[0.0], 10.0 ** np.arange(-16, -2.0)])
+    d = rng.choice(np.concatenate([eps, -eps]), n)
+    half = n // 2
+    # (1) tangent lines from random origins
+    ox = (rng.random(n) - 0.5) * spread * span[0] + span[0] / 2
+    oy = (rng.random(n) - 0.5) * spread * span[1] + span[1] / 2
+    dist = np.hypot(cx[k] - ox, cy[k] - oy)
+    phi = np.arctan2(cy[k] - oy, cx[k] - ox)
+    alpha = np.arcsin(np.clip(r[k] / np.maximum(dist, r[k] * 1.0001), -1, 1))
+    ang = phi + rng.choice([-1.0, 1.0], n) * alpha * (1.0 + d)
+    # (2) origins on (or a hair off) a rim, leaving radially, tangentially or a hair inward
+    th = rng.random(n) * 2 * np.pi
+    rim_x = cx[k] + r[k] * (1.0 + d) * np.cos(th)
+    rim_y = cy[k] + r[k] * (1.0 + d) * np.sin(th)
+    rim_ang = th + rng.choice([0.0, np.pi / 2, -np.pi / 2, np.pi], n) + rng.choice(np.concatenate([eps, -eps]), n)
+    sel = np.arange(n) >= half
+    ox, oy, ang = np.where(sel, rim_x, ox), np.where(sel, rim_y, oy), np.where(sel, rim_ang, ang)
+    return ox, oy, np.cos(ang), np.sin(ang), rng.integers(0, 95, n).astype(np.int32)
+
+
+@pytest.mark.parametrize("name", ["complex_world", "sample_world", "cornell_box"])
+def test_grazing_and_rim_rays(name, gpu_ctx, oracle):
+    world = rt.World2D(name, seed=1)
+    scene = rt.Scene2D(gpu_ctx, world)
+    rays = _grazing_rays(world, 100_000, seed=5)
+    compare(scene.trace_batch(*rays, depth=10, seed=3), oracle.trace_batch2d(world, *rays, depth=10, seed=3))
+    scene.close()
+
+
+@pytest.mark.parametrize("spread", [3.0, 7.9, 40.0, 1e6])
+def test_origins_far_outside_the_scene(spread, gpu_ctx, oracle):
+    """First origins up to and beyond the range the first-phase filter is built for (those take the unfiltered path)."""
+    world = rt.World2D("complex_world", seed=1)
+    scene = rt.Scene2D(gpu_ctx, world)
+    n = 20_000
+    rays = _grazing_rays(world, n, seed=8, spread=spread)
+    sel = np.arange(n) < n // 2   # only the far-origin half; the rim half is covered above
+    rays = tuple(x[sel] for x in rays)
+    compare(scene.trace_batch(*rays, depth=10, seed=3), oracle.trace_batch2d(world, *rays, depth=10, seed=3))
+    scene.close()
+
+
+def test_scene_far_from_the_coordinate_origin(gpu_ctx, oracle):
+    """The same circles moved to (1e7, -3e6): hit tests lose absolute precision there, and must lose it identically."""
+    base = rt.World2D("complex_world", seed=1).arrays()
+    a = dict(base)
+    a["circle_cx"] = base["circle_cx"] + 1.0e7
+    a["circle_cy"] = base["circle_cy"] - 3.0e6
+    world = rt.ArrayWorld2D(a)
+    scene = rt.Scene2D(gpu_ctx, world)
+    ox, oy, dx, dy, li = _grazing_rays(rt.World2D("complex_world", seed=1), 50_000, seed=2)
+    args = (ox + 1.0e7, oy - 3.0e6, dx, dy, li)
+    compare(scene.trace_batch(*args, depth=10, seed=3), oracle.trace_batch2d(world, *args, depth=10, seed=3))
+    scene.close()
+
+
+def test_context_outlives_its_scenes():
+    from raytracer_amd import _ffi
+    ctx = rt.Context(0)
+    scene = rt.Scene2D(ctx, rt.World2D("simple_world"))
+    assert _ffi.lib().rt_ctx_destroy(ctx._ctx) == -1  # RT_E_INVALID: a scene is still alive
+    assert b"scene" in _ffi.lib().rt_last_error()
+    ctx.close()            # closes the scene first, then the context
+    assert scene._sc is None and ctx._ctx is None
