@@ -106,6 +106,19 @@ class Standalone3D:
         self.close()
 
 
+class ArrayScene3D:
+    """rt3d_scene_desc over caller-owned sphere arrays and a Camera::new argument set (3d/src/rt.rs:139-147)."""
+
+    def __init__(self, cx, cy, cz, r, cam_pos, cam_dir, cam_up, focal_length, width, height, use_bvh=True):
+        self._a = [np.ascontiguousarray(v, np.float64) for v in (cx, cy, cz, r)]
+        d = self.desc = Scene3DDesc()
+        d.n_spheres, d.use_bvh = len(self._a[0]), 1 if use_bvh else 0
+        d.cx, d.cy, d.cz, d.r = (_ffi.ptr(v, C.c_double) for v in self._a)
+        for k in range(3):
+            d.cam_pos[k], d.cam_dir[k], d.cam_up[k] = float(cam_pos[k]), float(cam_dir[k]), float(cam_up[k])
+        d.focal_length, d.width, d.height = float(focal_length), int(width), int(height)
+
+
 class Context:
     """One GPU.  Work is enqueued on `stream` (a hipStream_t handle, e.g.
     torch.cuda.current_stream().cuda_stream) or on the context's own stream."""

@@ -1,0 +1,194 @@
+"""Randomly generated scenes through the C ABI against the CPU checker: every material kind on circles and
+segments, objects made of several primitives, primitive counts around the kernels' 32-slot words and
+256-slot tiles, odd circle counts, degenerate primitives; 3d sphere sets with and without an oversized sphere,
+linear scan and BVH.  Same bar as the fixed scenes: primitive ids, bounce counts and hit distances bit-exact,
+radiance to 1e-5 relative."""
+import numpy as np
+import pytest
+
+import raytracer_amd as rt
+from raytracer_amd.api import params2d, params3d
+
+pytestmark = pytest.mark.gpu
+
+EMISSIVE, DIRECTIONAL, DIFFUSE, REFLECTIVE, DIELECTRIC = range(5)
+
+
+def random_world2d(rng, n_circ, n_seg, span=(800.0, 600.0), degenerate=False):
+    """Objects as the reference has them (rt_common.rs:20-29): a circle, or a strip = a run of 1..4 segments;
+    scan order = object order, then position in the strip, and a primitive's pid is its place in that order."""
+    runs = []
+    left = n_seg
+    while left > 0:
+        k = min(left, int(rng.integers(1, 5)))
+        runs.append(k)
+        left -= k
+    kinds = ["c"] * n_circ + ["s"] * len(runs)
+    kinds = [kinds[i] for i in rng.permutation(len(kinds))]
+    n_obj = max(1, len(kinds))
+    n_sp = 6
+    spectra = rng.random((n_sp, 95)).astype(np.float32)
+    spectra[0] = 0.0                       # a black absorber: Diffuse short-circuits on it
+    spectra[1] *= 0.02                     # a weak Beer-Lambert absorption
+    mats = np.zeros((n_obj, 7))
+    for i in range(n_obj):
+        mats[i] = (rng.integers(0, 5), rng.integers(0, 2), rng.uniform(1.1, 1.8), rng.uniform(0.0, 0.05),
+                   rng.uniform(-1.0, 1.0), rng.uniform(0.1, 10.0), rng.integers(0, n_sp))
+    cobj, cpid, sobj, spid = [], [], [], []
+    pid, run = 0, 0
+    for o, kind in enumerate(kinds):
+        if kind == "c":
+            cobj.append(o); cpid.append(pid); pid += 1
+        else:
+            for _ in range(runs[run]):
+                sobj.append(o); spid.append(pid); pid += 1
+            run += 1
+    a = {"materials": mats, "spectra": spectra}
+    a["circle_cx"] = rng.random(n_circ) * span[0]
+    a["circle_cy"] = rng.random(n_circ) * span[1]
+    a["circle_r"] = np.exp(rng.uniform(np.log(0.5), np.log(40.0), n_circ))
+    a["circle_obj"] = np.array(cobj, np.int32)
+    a["circle_pid"] = np.array(cpid, np.int32)
+    ax, ay = rng.random(n_seg) * span[0], rng.random(n_seg) * span[1]
+    ang, ln = rng.random(n_seg) * 2 * np.pi, rng.uniform(1.0, 150.0, n_seg)
+    bx, by = ax + ln * np.cos(ang), ay + ln * np.sin(ang)
+    # chain the segments of a strip end to start, as a polyline (shared vertices are hit by two segments at once)
+    for k in range(1, n_seg):
+        if sobj[k] == sobj[k - 1]:
+            dxk, dyk = bx[k] - ax[k], by[k] - ay[k]
+            ax[k], ay[k] = bx[k - 1], by[k - 1]
+            bx[k], by[k] = ax[k] + dxk, ay[k] + dyk
+    if degenerate and n_seg >= 2:
+        bx[0], by[0] = ax[0], ay[0]        # zero-length segment: every ray is "parallel" to it
+        by[1] = ay[1]                      # axis-parallel
+    if degenerate and n_circ >= 2:
+        a["circle_r"][0] = 1e-9            # next to a point (the ABI rejects radii below 2^-400)
+        a["circle_cx"][1], a["circle_cy"][1] = a["circle_cx"][0], a["circle_cy"][0]  # concentric pair
+    # Segment::new: n = (b - a).perp().normalize() = (-sy, sx) * (1 / len)   (rt_common.rs:233-240)
+    sx, sy = bx - ax, by - ay
+    with np.errstate(divide="ignore", invalid="ignore"):
+        rl = 1.0 / np.sqrt((-sy) * (-sy) + sx * sx)
+        nx, ny = (-sy) * rl, sx * rl
+    bad = ~np.isfinite(nx) | ~np.isfinite(ny)
+    nx[bad], ny[bad] = 1.0, 0.0            # the ABI wants finite values; a zero-length segment is never hit
+    a.update(seg_ax=ax, seg_ay=ay, seg_bx=bx, seg_by=by, seg_nx=nx, seg_ny=ny)
+    a["seg_obj"] = np.array(sobj, np.int32)
+    a["seg_pid"] = np.array(spid, np.int32)
+    return rt.ArrayWorld2D(a)
+
+
+def rays2d(world, n, rng, span=(800.0, 600.0)):
+    ox, oy = rng.random(n) * span[0], rng.random(n) * span[1]
+    ang = rng.random(n) * 2 * np.pi
+    a = world._a
+    if len(a["circle_cx"]):
+        # a third of the rays graze a circle's rim
+        k = rng.integers(0, len(a["circle_cx"]), n)
+        dist = np.hypot(a["circle_cx"][k] - ox, a["circle_cy"][k] - oy)
+        r = a["circle_r"][k]
+        phi = np.arctan2(a["circle_cy"][k] - oy, a["circle_cx"][k] - ox)
+        alpha = np.arcsin(np.clip(r / np.maximum(dist, r * 1.0001 + 1e-300), -1, 1))
+        d = rng.choice([0.0, 1e-15, -1e-15, 1e-12, -1e-12, 1e-8, -1e-8, 1e-4, -1e-4], n)
+        graze = phi + rng.choice([-1.0, 1.0], n) * alpha * (1.0 + d)
+        ang = np.where(rng.random(n) < 1 / 3, graze, ang)
+    if len(a["seg_ax"]):
+        # and some start exactly on a segment end point or aim at one
+        k = rng.integers(0, len(a["seg_ax"]), n)
+        on = rng.random(n) < 0.1
+        ox, oy = np.where(on, a["seg_bx"][k], ox), np.where(on, a["seg_by"][k], oy)
+        aim = (rng.random(n) < 0.1) & ~on
+        ang = np.where(aim, np.arctan2(a["seg_ay"][k] - oy, a["seg_ax"][k] - ox), ang)
+    return ox, oy, np.cos(ang), np.sin(ang), rng.integers(0, 95, n).astype(np.int32)
+
+
+def compare2d(got, want):
+    rad, fp, ft, nb = got
+    orad, ofp, oft, onb = want
+    assert np.array_equal(fp, ofp)
+    assert np.array_equal(nb, onb)
+    assert np.array_equal(ft, oft)
+    assert np.allclose(rad, orad, rtol=1e-5, atol=1e-30)
+
+
+@pytest.mark.parametrize("n_circ,n_seg", [(1, 0), (0, 1), (31, 1), (33, 0), (200, 57), (255, 2), (256, 0), (1, 256),
+                                          (300, 300), (701, 5)])
+def test_random_world_fed_batch(n_circ, n_seg, gpu_ctx, oracle):
+    rng = np.random.default_rng(1000 * n_circ + n_seg)
+    world = random_world2d(rng, n_circ, n_seg, degenerate=(n_circ + n_seg) > 60)
+    scene = rt.Scene2D(gpu_ctx, world)
+    rays = rays2d(world, 30_000, rng)
+    compare2d(scene.trace_batch(*rays, depth=10, seed=5), oracle.trace_batch2d(world, *rays, depth=10, seed=5))
+    scene.close()
+
+
+@pytest.mark.parametrize("n_circ,n_seg,w,h", [(40, 25, 24, 16), (7, 300, 19, 9)])
+def test_random_world_render(n_circ, n_seg, w, h, gpu_ctx, oracle):
+    rng = np.random.default_rng(77 + n_circ)
+    world = random_world2d(rng, n_circ, n_seg)
+    scene = rt.Scene2D(gpu_ctx, world)
+    p = params2d(w, h, 3, 2, 10, seed=21)
+    gpu_ctx.reset_stats()
+    rgb, weight, spec = scene.global_render(p, want_spectrum=True)
+    st = gpu_ctx.stats()
+    orgb, ow, ospec, orays = oracle.render2d(world, p, threads=4, want_spectrum=True)
+    assert st["rays"] == orays
+    assert np.allclose(spec, ospec, rtol=1e-5, atol=1e-7)
+    assert np.allclose(rgb, orgb, rtol=1e-4, atol=1e-6)
+    scene.close()
+
+
+def random_scene3d(rng, n, giant, use_bvh, w=32, h=24):
+    c = rng.uniform(-20.0, 20.0, (n, 3))
+    r = np.exp(rng.uniform(np.log(0.1), np.log(3.0), n))
+    if giant and n >= 2:
+        c[n - 1], r[n - 1] = (0.0, -5020.0, 0.0), 5000.0
+    if n >= 4:
+        c[1] = c[0]                        # concentric pair, then an exact duplicate: ties go to the lower index
+        c[3], r[3] = c[2], r[2]
+    d = np.array([0.2, -0.1, -1.0])
+    d /= np.linalg.norm(d)
+    up = np.cross(np.cross(d, [0.0, 1.0, 0.0]), d)
+    up /= np.linalg.norm(up)
+    return rt.ArrayScene3D(c[:, 0], c[:, 1], c[:, 2], r, (1.0, 3.0, 30.0), d, up, 1.5, w, h, use_bvh=use_bvh)
+
+
+def compare3d(got, want):
+    for x, y in zip(got[1:], want[1:]):
+        assert np.array_equal(x, y)
+    assert np.allclose(got[0], want[0], rtol=1e-5, atol=1e-30)
+
+
+@pytest.mark.parametrize("use_bvh", [False, True])
+@pytest.mark.parametrize("n,giant", [(1, False), (2, True), (3, False), (64, True), (257, False), (1000, True)])
+def test_random_spheres_fed_batch(n, giant, use_bvh, gpu_ctx, oracle):
+    rng = np.random.default_rng(10 * n + giant)
+    s = random_scene3d(rng, n, giant, use_bvh)
+    scene = rt.Scene3D(gpu_ctx, s)
+    m = 30_000
+    o = rng.uniform(-25.0, 25.0, (m, 3))
+    d = rng.normal(0, 1, (m, 3))
+    # a third of the rays aim at a sphere's rim
+    k = rng.integers(0, n, m)
+    c = np.stack([s._a[0][k], s._a[1][k], s._a[2][k]], 1)
+    t = rng.normal(0, 1, (m, 3))
+    t -= (t * (c - o)).sum(1, keepdims=True) * (c - o) / ((c - o) ** 2).sum(1, keepdims=True)
+    t /= np.linalg.norm(t, axis=1, keepdims=True)
+    rim = c + t * s._a[3][k][:, None] * (1.0 + rng.choice([0.0, 1e-15, -1e-15, 1e-9, -1e-9, 1e-4], m))[:, None]
+    d = np.where((rng.random(m) < 1 / 3)[:, None], rim - o, d)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    compare3d(scene.trace_batch(o, d, 10, seed=8), oracle.trace_batch3d(s, o, d, 10, seed=8))
+    scene.close()
+
+
+@pytest.mark.parametrize("use_bvh", [False, True])
+def test_random_spheres_render(use_bvh, gpu_ctx, oracle):
+    rng = np.random.default_rng(4)
+    s = random_scene3d(rng, 300, True, use_bvh, w=36, h=20)
+    scene = rt.Scene3D(gpu_ctx, s)
+    p = params3d(3, 10, seed=2)
+    gpu_ctx.reset_stats()
+    img = scene.render(p)
+    oimg, orays = oracle.render3d(s, p)
+    assert gpu_ctx.stats()["rays"] == orays
+    assert np.allclose(img, oimg, rtol=1e-5, atol=1e-7)
+    scene.close()
