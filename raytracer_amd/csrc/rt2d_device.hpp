@@ -81,7 +81,7 @@ RT_DEV bool segment_t(double ox, double oy, double rx, double ry, double ax, dou
 }
 
 // ---------------------------------------------------------------------------
-// Nearest hit over the whole scene, brute force, in two phases per tile of 256
+// Nearest hit over the whole scene, brute force, in two phases per word of 32
 // slots:
 //  phase 1 (uniform loop, every lane x every primitive; primitives arrive as
 //    scalar operands): a cheap test marks the lanes for which the primitive can
@@ -113,10 +113,10 @@ RT_DEV bool segment_t(double ox, double oy, double rx, double ry, double ax, dou
 //      (|.| >= 2^-900) and differs in sign from den, or when |un| exceeds |den| by
 //      more than 2^-20 relative; scene and ray magnitudes are validated so
 //      |den| <= 2^62 and such a quotient cannot round to -0.0.
-//  phase 2 (per-lane loop over its marked slots, ascending): the exact test in
-//    the reference's operation order, then (total_cmp key, pid) lexicographic
-//    minimum = "first minimum in scan order" (librt2d_reverse.rs:139).
-// Inactive lanes run phase 1 with the wave and skip phase 2.
+//  phase 2 (marked slots only, shared out over the wave's lanes, see nearest_hit):
+//    the exact test in the reference's operation order, then (total_cmp key, pid)
+//    lexicographic minimum = "first minimum in scan order" (librt2d_reverse.rs:139).
+// Inactive lanes run phase 1 with the wave and mark nothing.
 // Per-ray operands of the circle filter, each duplicated into both halves of a packed register.
 struct FilterRay {
     f32x2 ndx, ndy; // -d
@@ -186,73 +186,118 @@ RT_DEV uint32_t filter_word(const SceneDev &S, int lo, int hi, double ox, double
     return (acc << (32 - (hi - lo))) | force;
 }
 
-RT_DEV Hit nearest_hit(const SceneDev &S, double ox, double oy, double dx, double dy, bool active, Prof &prof)
+// Per-wave LDS of nearest_hit's second phase.
+struct CoopLds {
+    int64_t key[64];      // running minimum total_cmp key of each lane's ray
+    uint64_t pidslot[64]; // (pid << 32 | slot) of the lowest pid among the hits that have that key
+    // queue of candidate words: mask (MSB = the word's first slot) and owner lane | word index within the 256-slot tile << 6
+    uint32_t ring_bits[128];
+    uint16_t ring_info[128];
+};
+
+// Phase 2 is shared by the wave.  A lane's own candidates are few (1.8 on average on the stress scene)
+// but a per-lane loop runs for the MAXIMUM over the wave (6.3 there) at ~30 % lane use.  Instead every
+// non-empty 32-slot mask word becomes an entry (owner lane, word, bits) in an LDS ring, appended with one
+// ballot + rank; whenever 64 entries are queued (and once more at the end) each lane takes ONE entry,
+// fetches the owner's ray by cross-lane permute, runs the exact test on the entry's first slot and puts
+// the rest of the entry, if any, back in the queue.  Results meet in the owner's LDS cell: an atomic
+// minimum on the total_cmp key, then - among the lanes holding that key - an atomic minimum on
+// (pid, slot); a lane that lowers the key clears the pid cell first (the two steps are separated by the
+// wave's in-order LDS execution).  The outcome is the minimum over all candidates of (key, pid): the
+// order of evaluation does not matter.  The ring never overflows: fewer than 64 entries are queued when
+// a word (<= 64 entries) is appended, and a round puts back at most what it took.
+RT_DEV Hit nearest_hit(const SceneDev &S, double ox, double oy, double dx, double dy, bool active, CoopLds &L, Prof &prof)
 {
-    Hit best;
-    best.t = 0.0;
-    best.slot = -1;
-    best.pid = 0x7fffffff;
-    int64_t best_key = 0x7fffffffffffffffLL;
     const int P = S.n_circ + S.n_seg;
+    const int lane = lane_id();
     // outside the frame the f32 filter is proven for, every slot becomes a candidate (exact tests decide)
     bool in_range;
     const FilterRay fr = filter_ray(S, ox, oy, dx, dy, in_range);
     const uint32_t force = in_range ? 0u : 0xFFFFFFFFu;
-    for (int base = 0; base < P; base += 256) {
-        uint32_t m[8];
-#pragma unroll
-        for (int w = 0; w < 8; ++w) {
-            const int lo = base + 32 * w;
-            const int hi = (lo + 32 < P) ? lo + 32 : P;
-            // bits below the word's last slot are shifted-in zeros; `force` may set them, so mask to the valid slots
-            const uint32_t valid = 0xFFFFFFFFu << (32 - ((lo < P) ? hi - lo : 32));
-            m[w] = (lo < P) ? (filter_word(S, lo, hi, ox, oy, dx, dy, fr, force) & valid) : 0u;
-        }
-        uint64_t m0 = ((uint64_t)m[0] << 32) | m[1], m1 = ((uint64_t)m[2] << 32) | m[3];
-        uint64_t m2 = ((uint64_t)m[4] << 32) | m[5], m3 = ((uint64_t)m[6] << 32) | m[7];
-        if (!active) { m0 = m1 = m2 = m3 = 0; }
+    L.key[lane] = 0x7fffffffffffffffLL;
+    L.pidslot[lane] = ~0ull;
+    int head = 0, count = 0; // wave-uniform
+    for (int lo = 0; lo < P; lo += 32) {
+        const int hi = (lo + 32 < P) ? lo + 32 : P;
+        // bits below the word's last slot are shifted-in zeros; `force` may set them, so mask to the valid slots
+        const uint32_t valid = 0xFFFFFFFFu << (32 - (hi - lo));
+        uint32_t mw = filter_word(S, lo, hi, ox, oy, dx, dy, fr, force) & valid;
+        if (!active) mw = 0u;
+        RT_STAMP(prof, 1);
 #ifdef RT_PROF
         {
-            int cnt = __popcll(m0) + __popcll(m1) + __popcll(m2) + __popcll(m3), mx = cnt;
-            for (int off = 32; off > 0; off >>= 1) { cnt += __shfl_xor(cnt, off); mx = max(mx, __shfl_xor(mx, off)); }
+            int cnt = __popc(mw);
+            for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off);
             prof.t[10] += (unsigned long long)cnt;
-            prof.t[11] += (unsigned long long)mx;
         }
 #endif
-        RT_STAMP(prof, 1);
-        while ((m0 | m1 | m2 | m3) != 0) {
-            const int w = m0 ? 0 : m1 ? 1 : m2 ? 2 : 3;
-            const uint64_t cur = m0 ? m0 : m1 ? m1 : m2 ? m2 : m3;
-            const int b = __clzll((long long)cur);
-            const uint64_t rest = cur & ~(0x8000000000000000ULL >> b);
-            m0 = (w == 0) ? rest : m0;
-            m1 = (w == 1) ? rest : m1;
-            m2 = (w == 2) ? rest : m2;
-            m3 = (w == 3) ? rest : m3;
-            const int s = base + 64 * w + b;
-            double t;
-            bool got;
-            int pid;
-            if (s < S.n_circ) {
-                got = circle_t(ox, oy, dx, dy, S.ccx[s], S.ccy[s], S.cr2[s], t);
-                pid = S.cpid[s];
-            } else {
-                const int k = s - S.n_circ;
-                got = segment_t(ox, oy, dx, dy, S.sax[k], S.say[k], S.ssx[k], S.ssy[k], t);
-                pid = S.spid[k];
+        const uint64_t fresh = __ballot(mw != 0u);
+        if (fresh != 0) {
+            if (mw != 0u) {
+                const int at = (head + count + rank_in_mask(fresh)) & 127;
+                L.ring_bits[at] = mw;
+                L.ring_info[at] = (uint16_t)(lane | ((lo & 255) << 1)); // (lo & 255) / 32 << 6
             }
-            if (got) {
-                const int64_t key = total_key(t);
-                if (key < best_key || (key == best_key && pid < best.pid)) {
-                    best_key = key;
-                    best.t = t;
-                    best.slot = s;
-                    best.pid = pid;
+            count += __popcll(fresh);
+        }
+        const bool last = hi == P || (hi & 255) == 0; // the queue is drained at the end of every 256-slot tile
+        const int base = lo & ~255;
+        while (count >= 64 || (last && count > 0)) {
+            const int n = count < 64 ? count : 64;
+            const bool has = lane < n;
+            const uint32_t ebits = L.ring_bits[(head + lane) & 127];
+            const uint32_t info = L.ring_info[(head + lane) & 127];
+            head = (head + n) & 127;
+            count -= n;
+            const uint32_t bits = has ? ebits : 0u;
+            const int owner = (int)(info & 63u);
+            const double rox = __shfl(ox, owner), roy = __shfl(oy, owner), rdx = __shfl(dx, owner), rdy = __shfl(dy, owner);
+            const int b = __clz((int)bits) & 31;
+            const uint32_t rest = bits & ~(0x80000000u >> b);
+            const int s = base + (int)((info & ~63u) >> 1) + b;
+            bool got = false;
+            double t = 0.0;
+            int pid = 0;
+            if (has) {
+                if (s < S.n_circ) {
+                    got = circle_t(rox, roy, rdx, rdy, S.ccx[s], S.ccy[s], S.cr2[s], t);
+                    pid = S.cpid[s];
+                } else {
+                    const int k = s - S.n_circ;
+                    got = segment_t(rox, roy, rdx, rdy, S.sax[k], S.say[k], S.ssx[k], S.ssy[k], t);
+                    pid = S.spid[k];
                 }
             }
+            const int64_t key = total_key(t);
+            if (got) {
+                const int64_t old = __hip_atomic_fetch_min(&L.key[owner], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (key < old) L.pidslot[owner] = ~0ull;
+            }
+            if (got && L.key[owner] == key)
+                __hip_atomic_fetch_min(&L.pidslot[owner], ((uint64_t)(uint32_t)pid << 32) | (uint64_t)(uint32_t)s, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_WORKGROUP);
+            const uint64_t again = __ballot(rest != 0u);
+            if (again != 0) {
+                if (rest != 0u) {
+                    const int at = (head + count + rank_in_mask(again)) & 127;
+                    L.ring_bits[at] = rest;
+                    L.ring_info[at] = (uint16_t)info;
+                }
+                count += __popcll(again);
+            }
+#ifdef RT_PROF
+            prof.t[11] += 1;
+#endif
         }
         RT_STAMP(prof, 2);
     }
+    Hit best;
+    const int64_t bk = L.key[lane];
+    const uint64_t ps = L.pidslot[lane];
+    const bool found = bk != 0x7fffffffffffffffLL;
+    best.t = found ? __longlong_as_double(bk ^ (int64_t)((uint64_t)(bk >> 63) >> 1)) : 0.0; // total_key is an involution
+    best.slot = found ? (int32_t)(uint32_t)ps : -1;
+    best.pid = found ? (int32_t)(ps >> 32) : 0x7fffffff;
     return best;
 }
 

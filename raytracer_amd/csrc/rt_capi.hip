@@ -529,7 +529,7 @@ int32_t launch_render2d(rt_ctx *ctx, const rt2d_scene *scene, const rt2d_render_
     A.k0 = (uint32_t)p->seed; A.k1 = (uint32_t)(p->seed >> 32);
     A.px_to_world = p->px_to_world;
     A.list_mode = list_mode;
-    A.tiles_x = (p->width + 7) / 8;
+    A.tiles_x = (p->width + rtk::TILE2D_W - 1) / rtk::TILE2D_W;
     A.list_px = d_px; A.list_py = d_py; A.n_list = n_list;
     A.out = d_out;
     A.ray_counter = ctx->d_rays;
@@ -543,8 +543,8 @@ int32_t launch_render2d(rt_ctx *ctx, const rt2d_scene *scene, const rt2d_render_
         A.prof_out = d_prof;
     }
 #endif
-    int64_t tiles = list_mode ? (n_list + rtk::TILE_PIXELS - 1) / rtk::TILE_PIXELS
-                              : (int64_t)A.tiles_x * ((p->height + 7) / 8);
+    int64_t tiles = list_mode ? (n_list + rtk::TILE2D_PIXELS - 1) / rtk::TILE2D_PIXELS
+                              : (int64_t)A.tiles_x * ((p->height + rtk::TILE2D_H - 1) / rtk::TILE2D_H);
     if (tiles <= 0) return RT_OK;
     if (tiles > 0x7fffffffLL) return fail(RT_E_LIMIT, "too many tiles");
     std::pair<hipEvent_t, hipEvent_t> ev;
@@ -562,7 +562,7 @@ int32_t launch_render2d(rt_ctx *ctx, const rt2d_scene *scene, const rt2d_render_
         HIP_TRY(hipStreamSynchronize(ctx->stream));
         HIP_TRY(hipMemcpy(h, A.prof_out, sizeof h, hipMemcpyDeviceToHost));
         const double tot = (double)(h[0] + h[1] + h[2] + h[3] + h[4] + h[7] + h[8] + h[9] + h[12] + h[13]);
-        fprintf(stderr, "[rt_prof] candidates per wave-step %.1f, phase-2 iterations (max over lanes) %.2f\n", (double)h[10] / (double)h[5],
+        fprintf(stderr, "[rt_prof] candidates per wave-step %.1f, phase-2 rounds per wave-step %.2f\n", (double)h[10] / (double)h[5],
                 (double)h[11] / (double)h[5]);
         fprintf(stderr, "[rt_prof] regen %.3f phase1 %.3f phase2 %.3f classify %.3f normal %.3f bend %.3f shade-rest %.3f hemisphere %.3f tail %.3f loop %.3f | wave_steps %llu lanes/step %.2f cycles/step %.0f\n",
                 h[0] / tot, h[1] / tot, h[2] / tot, h[7] / tot, h[8] / tot, h[9] / tot, h[12] / tot, h[13] / tot, h[3] / tot, h[4] / tot, h[5],

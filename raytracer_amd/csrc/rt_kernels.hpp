@@ -15,7 +15,10 @@
 namespace rtk {
 using namespace rtd;
 
-constexpr int TILE_PIXELS = 64; // 8 x 8
+constexpr int TILE_PIXELS = 64; // 3d: 8 x 8
+// 2d: 8 x 6 pixels.  The tile's spectral accumulator (48 x 95 f32) and the waves' candidate queues share LDS;
+// 6 workgroups per CU must fit in 160 KB (each wave drops by a fifth at 5).
+constexpr int TILE2D_W = 8, TILE2D_H = 6, TILE2D_PIXELS = TILE2D_W * TILE2D_H;
 constexpr int BLOCK = 256;
 
 struct Render2dArgs {
@@ -23,7 +26,7 @@ struct Render2dArgs {
     int32_t width, height, spp, lambda_samples, recursion_limit, sample_offset;
     uint32_t k0, k1;
     double px_to_world;
-    int32_t list_mode; // 0: 8x8 image tiles, accumulate into out[W*y+x][95]; 1: pixel list, out[k][95] = mean
+    int32_t list_mode; // 0: 8x6 image tiles, accumulate into out[W*y+x][95]; 1: pixel list, out[k][95] = mean
     int32_t tiles_x;
     const int32_t *list_px, *list_py;
     int64_t n_list;
@@ -37,18 +40,19 @@ struct Render2dArgs {
 // (2d/src/librt2d_reverse.rs:80-110), fused with trace_ray (:112-262).
 __global__ __launch_bounds__(BLOCK, 6) void render2d_kernel(const Render2dArgs A)
 {
-    __shared__ float acc[TILE_PIXELS * NBINS];
+    __shared__ float acc[TILE2D_PIXELS * NBINS];
     __shared__ int next_item;
+    __shared__ rt2d::CoopLds coop[BLOCK / 64];
     const int tid = threadIdx.x;
     const int tile = blockIdx.x;
-    for (int i = tid; i < TILE_PIXELS * NBINS; i += BLOCK) acc[i] = 0.0f;
+    for (int i = tid; i < TILE2D_PIXELS * NBINS; i += BLOCK) acc[i] = 0.0f;
     if (tid == 0) next_item = 0;
     __syncthreads();
 
     const int per_pixel = A.spp * A.lambda_samples;
-    const int total = TILE_PIXELS * per_pixel;
-    const int tx = A.list_mode ? 0 : (tile % A.tiles_x) * 8;
-    const int ty = A.list_mode ? 0 : (tile / A.tiles_x) * 8;
+    const int total = TILE2D_PIXELS * per_pixel;
+    const int tx = A.list_mode ? 0 : (tile % A.tiles_x) * TILE2D_W;
+    const int ty = A.list_mode ? 0 : (tile / A.tiles_x) * TILE2D_H;
     const float inv_scale_l = (float)A.lambda_samples;
 
     rt2d::Path p;
@@ -76,20 +80,20 @@ __global__ __launch_bounds__(BLOCK, 6) void render2d_kernel(const Render2dArgs A
             if (!alive) {
                 const int item = base + rank_in_mask(dead);
                 if (item < total) {
-                    const int lp = item & (TILE_PIXELS - 1);
-                    const int rest = item >> 6;
+                    const int rest = item / TILE2D_PIXELS;
+                    const int lp = item - rest * TILE2D_PIXELS;
                     const int l = rest % A.lambda_samples;
                     const int s = rest / A.lambda_samples;
                     int px, py;
                     bool valid;
                     if (A.list_mode) {
-                        const int64_t k = (int64_t)tile * TILE_PIXELS + lp;
+                        const int64_t k = (int64_t)tile * TILE2D_PIXELS + lp;
                         valid = k < A.n_list;
                         px = valid ? A.list_px[k] : 0;
                         py = valid ? A.list_py[k] : 0;
                     } else {
-                        px = tx + (lp & 7);
-                        py = ty + (lp >> 3);
+                        px = tx + lp % TILE2D_W;
+                        py = ty + lp / TILE2D_W;
                         valid = px < A.width && py < A.height;
                     }
                     if (valid) {
@@ -112,7 +116,7 @@ __global__ __launch_bounds__(BLOCK, 6) void render2d_kernel(const Render2dArgs A
         prof.t[5] += 1;
         prof.t[6] += (unsigned long long)__popcll(__ballot(run));
 #endif
-        const rt2d::Hit h = rt2d::nearest_hit(A.S, p.ox, p.oy, p.dx, p.dy, run, prof);
+        const rt2d::Hit h = rt2d::nearest_hit(A.S, p.ox, p.oy, p.dx, p.dy, run, coop[tid >> 6], prof);
         float value = 0.0f;
         double dnx = 0.0, dny = 0.0;
         rt2d::ShadeResult r = rt2d::SHADE_DONE;
@@ -150,13 +154,13 @@ __global__ __launch_bounds__(BLOCK, 6) void render2d_kernel(const Render2dArgs A
     if ((tid & 63) == 0 && nrays != 0) atomicAdd(A.ray_counter, nrays);
 
     __syncthreads();
-    for (int i = tid; i < TILE_PIXELS * NBINS; i += BLOCK) {
+    for (int i = tid; i < TILE2D_PIXELS * NBINS; i += BLOCK) {
         const int lp = i / NBINS, bin = i - lp * NBINS;
         if (A.list_mode) {
-            const int64_t k = (int64_t)tile * TILE_PIXELS + lp;
+            const int64_t k = (int64_t)tile * TILE2D_PIXELS + lp;
             if (k < A.n_list) A.out[k * NBINS + bin] = acc[i] / (float)A.spp; // `total_spectrum / spp` (:109)
         } else {
-            const int px = tx + (lp & 7), py = ty + (lp >> 3);
+            const int px = tx + lp % TILE2D_W, py = ty + lp / TILE2D_W;
             if (px < A.width && py < A.height) {
                 float *dst = A.out + ((int64_t)A.width * py + px) * NBINS + bin;
                 *dst = *dst + acc[i];
@@ -175,6 +179,7 @@ __global__ __launch_bounds__(BLOCK) void trace_batch2d_kernel(const rt2d::SceneD
                                                              int32_t *__restrict__ first_prim, double *__restrict__ first_t,
                                                              int32_t *__restrict__ bounces, unsigned long long *ray_counter)
 {
+    __shared__ rt2d::CoopLds coop[BLOCK / 64];
     const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     const bool in_range = i < n;
     rt2d::Path p;
@@ -193,7 +198,7 @@ __global__ __launch_bounds__(BLOCK) void trace_batch2d_kernel(const rt2d::SceneD
     while (__any(alive)) {
         const bool run = alive && p.depth_left > 0;
         Prof prof{};
-        const rt2d::Hit h = rt2d::nearest_hit(S, p.ox, p.oy, p.dx, p.dy, run, prof);
+        const rt2d::Hit h = rt2d::nearest_hit(S, p.ox, p.oy, p.dx, p.dy, run, coop[threadIdx.x >> 6], prof);
         float value = 0.0f;
         double dnx = 0.0, dny = 0.0;
         rt2d::ShadeResult r = rt2d::SHADE_DONE;
