@@ -68,7 +68,8 @@ struct rt_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
-    unsigned long long *d_rays = nullptr;
+    unsigned long long *d_rays = nullptr; // [0] rays traced, [1] (as int32) the 2d render kernel's tile counter
+    int n_cu = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending; // trace-kernel brackets not yet folded
     std::vector<std::pair<hipEvent_t, hipEvent_t>> free_events;
     double kernel_ms = 0.0;
@@ -197,8 +198,9 @@ int32_t rt_ctx_create(int32_t device_id, rt_ctx **out)
     ctx->device = device_id;
     HIP_TRY(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
     ctx->stream = ctx->own_stream;
-    HIP_TRY(hipMalloc((void **)&ctx->d_rays, sizeof(unsigned long long)));
-    HIP_TRY(hipMemset(ctx->d_rays, 0, sizeof(unsigned long long)));
+    HIP_TRY(hipMalloc((void **)&ctx->d_rays, 2 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(ctx->d_rays, 0, 2 * sizeof(unsigned long long)));
+    HIP_TRY(hipDeviceGetAttribute(&ctx->n_cu, hipDeviceAttributeMultiprocessorCount, ctx->device));
     *out = ctx;
     return RT_OK;
 }
@@ -533,6 +535,7 @@ int32_t launch_render2d(rt_ctx *ctx, const rt2d_scene *scene, const rt2d_render_
     A.list_px = d_px; A.list_py = d_py; A.n_list = n_list;
     A.out = d_out;
     A.ray_counter = ctx->d_rays;
+    A.tile_counter = reinterpret_cast<int32_t *>(ctx->d_rays + 1);
     A.refill_min = refill_threshold(scene->n_prims);
     A.prof_out = nullptr;
 #ifdef RT_PROF
@@ -546,14 +549,33 @@ int32_t launch_render2d(rt_ctx *ctx, const rt2d_scene *scene, const rt2d_render_
     int64_t tiles = list_mode ? (n_list + rtk::TILE2D_PIXELS - 1) / rtk::TILE2D_PIXELS
                               : (int64_t)A.tiles_x * ((p->height + rtk::TILE2D_H - 1) / rtk::TILE2D_H);
     if (tiles <= 0) return RT_OK;
-    if (tiles > 0x7fffffffLL) return fail(RT_E_LIMIT, "too many tiles");
+    if (tiles > 0x7fffffffLL - 65536) return fail(RT_E_LIMIT, "too many tiles");
+    A.n_tiles = (int32_t)tiles;
+    {
+        // work units of about 1024 items: small against a wave's share of the launch, large against the refill rate
+        const int64_t total = (int64_t)rtk::TILE2D_PIXELS * p->spp * p->lambda_samples;
+        const int64_t runs = std::max<int64_t>(1, std::min<int64_t>((total + 1023) / 1024, (0x7fffffffLL - 65536) / tiles));
+        A.chunk = (int32_t)((total + runs - 1) / runs);
+        A.n_units = (int32_t)(tiles * ((total + A.chunk - 1) / A.chunk));
+    }
+    // persistent waves: enough workgroups to fill every CU at 6 per CU, never more waves than tiles
+    const int waves_per_block = rtk::BLOCK / 64;
+    const int64_t blocks = std::min<int64_t>((tiles + waves_per_block - 1) / waves_per_block, (int64_t)std::max(ctx->n_cu, 1) * 6);
+    HIP_TRY(hipMemsetAsync(A.tile_counter, 0, sizeof(int32_t), ctx->stream));
+    if (list_mode) HIP_TRY(hipMemsetAsync(d_out, 0, sizeof(float) * (size_t)n_list * RT_NBINS, ctx->stream));
     std::pair<hipEvent_t, hipEvent_t> ev;
     if (int32_t rc = fold_events(ctx, 256)) return rc;
     if (int32_t rc = event_pair(ctx, &ev)) return rc;
     HIP_TRY(hipEventRecord(ev.first, ctx->stream));
-    hipLaunchKernelGGL(rtk::render2d_kernel, dim3((unsigned)tiles), dim3(rtk::BLOCK), 0, ctx->stream, A);
+    hipLaunchKernelGGL(rtk::render2d_kernel, dim3((unsigned)blocks), dim3(rtk::BLOCK), 0, ctx->stream, A);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(ev.second, ctx->stream));
+    if (list_mode) {
+        const int64_t nf = n_list * RT_NBINS;
+        hipLaunchKernelGGL(rtk::divide_kernel, dim3((unsigned)((nf + rtk::BLOCK - 1) / rtk::BLOCK)), dim3(rtk::BLOCK), 0, ctx->stream,
+                           d_out, nf, (float)p->spp);
+        HIP_TRY(hipGetLastError());
+    }
     ctx->pending.push_back(ev);
     ctx->launches += 1;
 #ifdef RT_PROF

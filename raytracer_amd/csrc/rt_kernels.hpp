@@ -16,8 +16,8 @@ namespace rtk {
 using namespace rtd;
 
 constexpr int TILE_PIXELS = 64; // 3d: 8 x 8
-// 2d: 8 x 6 pixels.  The tile's spectral accumulator (48 x 95 f32) and the waves' candidate queues share LDS;
-// 6 workgroups per CU must fit in 160 KB (each wave drops by a fifth at 5).
+// 2d: a work unit is 8 x 6 pixels (x all samples and lambda-samples) and belongs to ONE wave, so every
+// spectral bin it touches (48 x 380 B) is written by that wave only and stays in its XCD's L2.
 constexpr int TILE2D_W = 8, TILE2D_H = 6, TILE2D_PIXELS = TILE2D_W * TILE2D_H;
 constexpr int BLOCK = 256;
 
@@ -26,41 +26,46 @@ struct Render2dArgs {
     int32_t width, height, spp, lambda_samples, recursion_limit, sample_offset;
     uint32_t k0, k1;
     double px_to_world;
-    int32_t list_mode; // 0: 8x6 image tiles, accumulate into out[W*y+x][95]; 1: pixel list, out[k][95] = mean
+    int32_t list_mode; // 0: 8x6 image tiles, out[W*y+x][95] += sum; 1: pixel list, out[k][95] += sum (zeroed and scaled by the host side)
     int32_t tiles_x;
+    int32_t n_tiles;
+    int32_t chunk, n_units; // a tile's items are handed out in runs of `chunk`; unit u = run u / n_tiles of tile u % n_tiles
     const int32_t *list_px, *list_py;
     int64_t n_list;
     float *out;
     unsigned long long *ray_counter;
+    int32_t *tile_counter; // next unit to hand out, zeroed before the launch
     int32_t refill_min; // refill dead lanes once at least this many are dead (1..64)
     unsigned long long *prof_out; // diagnostic builds only
 };
 
-// ReverseRenderer::compute_pixel for every pixel of a tile
+// ReverseRenderer::compute_pixel for every pixel of the image or list
 // (2d/src/librt2d_reverse.rs:80-110), fused with trace_ray (:112-262).
+//
+// Waves are persistent and independent: each pulls work units (a run of one tile's (pixel, sample,
+// lambda-sample) items) from a global counter, and its lanes pull items from a wave-private cursor.  A lane
+// whose path ended is refilled in place, from the next unit when the current one runs out, so lanes idle
+// only once, at the end of the launch; units are small enough (about 1 k items) that the waves finish within
+// a few percent of each other, and they are numbered run-major so that the waves working at the same time are
+// on different tiles.  A finished sample is added to its pixel's bin in HBM with a hardware f32 atomic
+// (the tile's 18 KB stay in L2 while a unit lasts); nothing but the candidate queues lives in LDS.
 __global__ __launch_bounds__(BLOCK, 6) void render2d_kernel(const Render2dArgs A)
 {
-    __shared__ float acc[TILE2D_PIXELS * NBINS];
-    __shared__ int next_item;
     __shared__ rt2d::CoopLds coop[BLOCK / 64];
     const int tid = threadIdx.x;
-    const int tile = blockIdx.x;
-    for (int i = tid; i < TILE2D_PIXELS * NBINS; i += BLOCK) acc[i] = 0.0f;
-    if (tid == 0) next_item = 0;
-    __syncthreads();
+    const int lane = tid & 63;
 
     const int per_pixel = A.spp * A.lambda_samples;
     const int total = TILE2D_PIXELS * per_pixel;
-    const int tx = A.list_mode ? 0 : (tile % A.tiles_x) * TILE2D_W;
-    const int ty = A.list_mode ? 0 : (tile / A.tiles_x) * TILE2D_H;
     const float inv_scale_l = (float)A.lambda_samples;
 
     rt2d::Path p;
     p.ox = p.oy = p.dx = p.dy = 0.0;
     p.thr = 0.0f; p.li = 0; p.depth_left = 0; p.c0 = p.c1 = p.c2 = 0;
     bool alive = false;
-    bool wave_done = false;
-    int lpix = 0;
+    bool exhausted = false; // wave-uniform: no tile left
+    int tile = 0, cursor = 0, cursor_end = 0, tx = 0, ty = 0; // wave-uniform
+    int64_t opix = 0; // row of `out` this lane's path adds to
     unsigned long long nrays = 0;
     Prof prof{};
 #ifdef RT_PROF
@@ -71,43 +76,58 @@ __global__ __launch_bounds__(BLOCK, 6) void render2d_kernel(const Render2dArgs A
         RT_STAMP(prof, 4);
         const uint64_t dead = __ballot(!alive);
         const int ndead = __popcll(dead);
-        if (!wave_done && (ndead >= A.refill_min || ndead == 64)) {
-            int base = 0;
-            if (rank_in_mask(dead) == 0 && !alive) base = atomicAdd(&next_item, ndead);
-            // the first dead lane did the add; fetch its value
-            const int src = __ffsll((long long)dead) - 1;
-            base = __shfl(base, src);
-            if (!alive) {
-                const int item = base + rank_in_mask(dead);
-                if (item < total) {
-                    const int rest = item / TILE2D_PIXELS;
-                    const int lp = item - rest * TILE2D_PIXELS;
-                    const int l = rest % A.lambda_samples;
-                    const int s = rest / A.lambda_samples;
-                    int px, py;
-                    bool valid;
-                    if (A.list_mode) {
-                        const int64_t k = (int64_t)tile * TILE2D_PIXELS + lp;
-                        valid = k < A.n_list;
-                        px = valid ? A.list_px[k] : 0;
-                        py = valid ? A.list_py[k] : 0;
-                    } else {
-                        px = tx + lp % TILE2D_W;
-                        py = ty + lp / TILE2D_W;
-                        valid = px < A.width && py < A.height;
-                    }
-                    if (valid) {
-                        rt2d::generate(p, px, py, A.width, (uint32_t)(A.sample_offset + s), (uint32_t)l, A.px_to_world,
-                                       A.recursion_limit, A.k0, A.k1);
-                        lpix = lp;
-                        alive = true;
-                    }
+        if (!exhausted && (ndead >= A.refill_min || ndead == 64)) {
+            if (cursor >= cursor_end) {
+                int t = 0;
+                if (lane == 0) t = atomicAdd(A.tile_counter, 1);
+                const int unit = __builtin_amdgcn_readfirstlane(t);
+                if (unit >= A.n_units) {
+                    exhausted = true;
+                } else {
+                    const int run = unit / A.n_tiles;
+                    tile = unit - run * A.n_tiles;
+                    cursor = run * A.chunk;
+                    cursor_end = (cursor + A.chunk < total) ? cursor + A.chunk : total;
+                    tx = A.list_mode ? 0 : (tile % A.tiles_x) * TILE2D_W;
+                    ty = A.list_mode ? 0 : (tile / A.tiles_x) * TILE2D_H;
                 }
             }
-            if (base + ndead >= total) wave_done = true;
+            if (!exhausted) {
+                if (!alive) {
+                    const int item = cursor + rank_in_mask(dead);
+                    if (item < cursor_end) {
+                        const int rest = item / TILE2D_PIXELS;
+                        const int lp = item - rest * TILE2D_PIXELS;
+                        const int l = rest % A.lambda_samples;
+                        const int s = rest / A.lambda_samples;
+                        int px, py;
+                        bool valid;
+                        int64_t row;
+                        if (A.list_mode) {
+                            const int64_t k = (int64_t)tile * TILE2D_PIXELS + lp;
+                            valid = k < A.n_list;
+                            px = valid ? A.list_px[k] : 0;
+                            py = valid ? A.list_py[k] : 0;
+                            row = k;
+                        } else {
+                            px = tx + lp % TILE2D_W;
+                            py = ty + lp / TILE2D_W;
+                            valid = px < A.width && py < A.height;
+                            row = (int64_t)A.width * py + px;
+                        }
+                        if (valid) {
+                            rt2d::generate(p, px, py, A.width, (uint32_t)(A.sample_offset + s), (uint32_t)l, A.px_to_world,
+                                           A.recursion_limit, A.k0, A.k1);
+                            opix = row;
+                            alive = true;
+                        }
+                    }
+                }
+                cursor += ndead; // items past the unit's end are not handed out: those lanes refill from the next unit
+            }
         }
         if (!__any(alive)) {
-            if (wave_done) break;
+            if (exhausted) break;
             continue;
         }
         const bool run = alive && p.depth_left > 0;
@@ -135,7 +155,7 @@ __global__ __launch_bounds__(BLOCK, 6) void render2d_kernel(const Render2dArgs A
                     // per-sample term of `spectrum_spp / lambda_samples * 95` (librt2d_reverse.rs:104-105)
                     const float v = p.thr * value;
                     const float c = v / inv_scale_l * (float)NBINS;
-                    atomicAdd(&acc[lpix * NBINS + p.li], c);
+                    unsafeAtomicAdd(A.out + opix * NBINS + p.li, c);
                 }
                 alive = false;
             } else if (p.depth_left == 0) {
@@ -145,28 +165,20 @@ __global__ __launch_bounds__(BLOCK, 6) void render2d_kernel(const Render2dArgs A
         RT_STAMP(prof, 3);
     }
 #ifdef RT_PROF
-    if ((tid & 63) == 0 && A.prof_out)
+    if (lane == 0 && A.prof_out)
         for (int i = 0; i < 16; ++i) atomicAdd(A.prof_out + i, prof.t[i]);
 #endif
 
     // rays traced by this wave -> one global atomic
     for (int off = 32; off > 0; off >>= 1) nrays += __shfl_down(nrays, off);
-    if ((tid & 63) == 0 && nrays != 0) atomicAdd(A.ray_counter, nrays);
+    if (lane == 0 && nrays != 0) atomicAdd(A.ray_counter, nrays);
+}
 
-    __syncthreads();
-    for (int i = tid; i < TILE2D_PIXELS * NBINS; i += BLOCK) {
-        const int lp = i / NBINS, bin = i - lp * NBINS;
-        if (A.list_mode) {
-            const int64_t k = (int64_t)tile * TILE2D_PIXELS + lp;
-            if (k < A.n_list) A.out[k * NBINS + bin] = acc[i] / (float)A.spp; // `total_spectrum / spp` (:109)
-        } else {
-            const int px = tx + lp % TILE2D_W, py = ty + lp / TILE2D_W;
-            if (px < A.width && py < A.height) {
-                float *dst = A.out + ((int64_t)A.width * py + px) * NBINS + bin;
-                *dst = *dst + acc[i];
-            }
-        }
-    }
+// out[i] = out[i] / spp: `total_spectrum / spp` of compute_pixel (2d/src/librt2d_reverse.rs:109) for the pixel-list entry.
+__global__ __launch_bounds__(BLOCK) void divide_kernel(float *__restrict__ out, int64_t n, float spp)
+{
+    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i < n) out[i] = out[i] / spp;
 }
 
 // ReverseRenderer::trace_ray for a fed batch (2d/src/librt2d_reverse.rs:112-262),
