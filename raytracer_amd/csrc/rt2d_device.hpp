@@ -256,39 +256,46 @@ RT_DEV Hit nearest_hit(const SceneDev &S, double ox, double oy, double dx, doubl
             const uint32_t info = L.ring_info[(head + lane) & 127];
             head = (head + n) & 127;
             count -= n;
-            const uint32_t bits = has ? ebits : 0u;
+            uint32_t bits = has ? ebits : 0u;
             const int owner = (int)(info & 63u);
             const double rox = __shfl(ox, owner), roy = __shfl(oy, owner), rdx = __shfl(dx, owner), rdy = __shfl(dy, owner);
-            const int b = __clz((int)bits) & 31;
-            const uint32_t rest = bits & ~(0x80000000u >> b);
-            const int s = base + (int)((info & ~63u) >> 1) + b;
-            bool got = false;
-            double t = 0.0;
-            int pid = 0;
-            if (has) {
-                if (s < S.n_circ) {
-                    got = circle_t(rox, roy, rdx, rdy, S.ccx[s], S.ccy[s], S.cr2[s], t);
-                    pid = S.cpid[s];
-                } else {
-                    const int k = s - S.n_circ;
-                    got = segment_t(rox, roy, rdx, rdy, S.sax[k], S.say[k], S.ssx[k], S.ssy[k], t);
-                    pid = S.spid[k];
+            // the last round of a tile has idle lanes and nothing to ride along with: there a lane walks through all
+            // the slots of its entry; elsewhere it tests one and queues the rest again
+            const bool drain = last && count == 0;
+            do {
+                const int b = __clz((int)bits) & 31;
+                const bool on = bits != 0u;
+                bits &= ~(0x80000000u >> b);
+                const int s = base + (int)((info & ~63u) >> 1) + b;
+                bool got = false;
+                double t = 0.0;
+                int pid = 0;
+                if (on) {
+                    if (s < S.n_circ) {
+                        got = circle_t(rox, roy, rdx, rdy, S.ccx[s], S.ccy[s], S.cr2[s], t);
+                        pid = S.cpid[s];
+                    } else {
+                        const int k = s - S.n_circ;
+                        got = segment_t(rox, roy, rdx, rdy, S.sax[k], S.say[k], S.ssx[k], S.ssy[k], t);
+                        pid = S.spid[k];
+                    }
                 }
-            }
-            const int64_t key = total_key(t);
-            if (got) {
-                const int64_t old = __hip_atomic_fetch_min(&L.key[owner], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (key < old) L.pidslot[owner] = ~0ull;
-            }
-            __builtin_amdgcn_wave_barrier();
-            if (got && L.key[owner] == key)
-                __hip_atomic_fetch_min(&L.pidslot[owner], ((uint64_t)(uint32_t)pid << 32) | (uint64_t)(uint32_t)s, __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_WORKGROUP);
-            const uint64_t again = __ballot(rest != 0u);
+                const int64_t key = total_key(t);
+                if (got) {
+                    const int64_t old = __hip_atomic_fetch_min(&L.key[owner], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (key < old) L.pidslot[owner] = ~0ull;
+                }
+                __builtin_amdgcn_wave_barrier();
+                if (got && L.key[owner] == key)
+                    __hip_atomic_fetch_min(&L.pidslot[owner], ((uint64_t)(uint32_t)pid << 32) | (uint64_t)(uint32_t)s, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_WORKGROUP);
+                __builtin_amdgcn_wave_barrier();
+            } while (drain && __any(bits != 0u));
+            const uint64_t again = __ballot(bits != 0u);
             if (again != 0) {
-                if (rest != 0u) {
+                if (bits != 0u) {
                     const int at = (head + count + rank_in_mask(again)) & 127;
-                    L.ring_bits[at] = rest;
+                    L.ring_bits[at] = bits;
                     L.ring_info[at] = (uint16_t)info;
                 }
                 count += __popcll(again);

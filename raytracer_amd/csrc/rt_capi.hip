@@ -552,6 +552,14 @@ int32_t launch_render2d(rt_ctx *ctx, const rt2d_scene *scene, const rt2d_render_
     if (tiles > 0x7fffffffLL - 65536) return fail(RT_E_LIMIT, "too many tiles");
     A.n_tiles = (int32_t)tiles;
     {
+        int sh = 0;
+        while ((1u << sh) < (uint32_t)p->lambda_samples) ++sh;
+        const unsigned __int128 num = (unsigned __int128)1 << (32 + sh);
+        const unsigned __int128 m = (num + (uint32_t)p->lambda_samples - 1) / (uint32_t)p->lambda_samples;
+        A.ls_magic = (uint32_t)(m - ((unsigned __int128)1 << 32));
+        A.ls_shift = sh;
+    }
+    {
         // work units of about 1024 items: small against a wave's share of the launch, large against the refill rate
         const int64_t total = (int64_t)rtk::TILE2D_PIXELS * p->spp * p->lambda_samples;
         const int64_t runs = std::max<int64_t>(1, std::min<int64_t>((total + 1023) / 1024, (0x7fffffffLL - 65536) / tiles));

@@ -29,6 +29,10 @@ struct Render2dArgs {
     int32_t list_mode; // 0: 8x6 image tiles, out[W*y+x][95] += sum; 1: pixel list, out[k][95] += sum (zeroed and scaled by the host side)
     int32_t tiles_x;
     int32_t n_tiles;
+    // floor(x / lambda_samples) for x < 2^24 as (mulhi(x, ls_magic) + x) >> ls_shift: ls_shift = ceil(log2 lambda_samples),
+    // ls_magic = ceil(2^(32 + ls_shift) / lambda_samples) - 2^32 (exact: the error term x e / 2^(32 + shift) stays below 1 / lambda_samples)
+    uint32_t ls_magic;
+    int32_t ls_shift;
     int32_t chunk, n_units; // a tile's items are handed out in runs of `chunk`; unit u = run u / n_tiles of tile u % n_tiles
     const int32_t *list_px, *list_py;
     int64_t n_list;
@@ -98,8 +102,8 @@ __global__ __launch_bounds__(BLOCK, 6) void render2d_kernel(const Render2dArgs A
                     if (item < cursor_end) {
                         const int rest = item / TILE2D_PIXELS;
                         const int lp = item - rest * TILE2D_PIXELS;
-                        const int l = rest % A.lambda_samples;
-                        const int s = rest / A.lambda_samples;
+                        const int s = (int)((__umulhi((uint32_t)rest, A.ls_magic) + (uint32_t)rest) >> A.ls_shift);
+                        const int l = rest - s * A.lambda_samples;
                         int px, py;
                         bool valid;
                         int64_t row;
