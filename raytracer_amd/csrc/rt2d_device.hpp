@@ -36,12 +36,12 @@ typedef const double __attribute__((address_space(4))) *K_f64;
 // reference recomputes in every hit test (rt_common.rs:83, :244).
 struct SceneDev {
     int32_t n_circ, n_seg, n_obj, pad_; // n_circ is even: an odd circle count is padded with a circle nothing can hit
-    // circles as the f32 filter sees them (see filter_word), relative to the filter frame's centre
-    // (filt_mx, filt_my): c32x/c32y = centre - frame centre rounded to f32, c32e = r^2 (1 + 2^-21) - |c32|^2 rounded up
+    // circles as the f32 filter sees them (see filter_word): c32x/c32y = centre - frame centre (filt_mx, filt_my)
+    // rounded to f32; c32e = r^2 (1 + 2^-22) + filt_M rounded up, rewritten by pad_radii_kernel when filt_M changes
     const float *c32x, *c32y, *c32e;
-    // filter frame, set per launch: the filter is proven for |origin - centre|_inf <= filt_B and |dir|^2 <= 1.001;
-    // filt_eb = 2^-20 filt_B bounds the f32 error of d.(o-c), filt_M = 200 * 2^-24 filt_B^2 pads the squared radius
-    double filt_mx, filt_my, filt_B, filt_eb, filt_M;
+    // filter frame, set per launch: the filter is proven for |origin - centre|_inf <= filt_B and | |dir|^2 - 1 | <= 2^-40;
+    // filt_M = 64 * 2^-24 filt_B^2 pads the squared radius
+    double filt_mx, filt_my, filt_B, filt_M;
     const double *ior, *inv_ior; // [n_ior][95]: Ior::ior(lambda_i) and its reciprocal (rt_common.rs:442-450)
     const double *ccx, *ccy, *cr2;
     const double *sax, *say, *ssx, *ssy, *snx, *sny;
@@ -94,25 +94,22 @@ RT_DEV bool segment_t(double ox, double oy, double rx, double ry, double ax, dou
 //    still be a hit.  It decides with SIGN BITS only (no sqrt, division or
 //    compare) and it never drops a hit the reference would report:
 //    circle, in f32 with fused ops, in coordinates relative to the frame centre m:
-//      u = o - m, v = c - m (|u_i|, |v_i| <= B), bp = d.(u - v), l2 = |u - v|^2.  The
-//      reference needs D = bp^2 - l2 + r^2 >= 0 (its delta / 4) and a positive root,
-//      and has no positive root when bp > 0 and l2 > r^2.  Both are evaluated in
-//      expanded form so that a circle costs six packed operations:
-//        fbn   = (d.u - eb) - dy vy - dx vx            ~ bp - eb
-//        inner = (e - (|u|^2 - M)) + 2 uy vy + 2 ux vx ~ r^2 + pad - l2,  e = r^2 (1 + 2^-21) - |v|^2
-//        g     = fbn^2 + inner                         ~ D + pad
-//      with u, v, d rounded to f32 (eps = 2^-24, |d_i| <= 1.0005):
-//        |fbn - (bp - eb)| <= 10.7 eps B  (roundings of d.u - eb, the two fused steps, and of
-//          the inputs), so with eb = 16 eps B: fbn >= 0 implies bp >= 5.3 eps B > 0, and
-//          |fbn - bp| <= 26.7 eps B;
-//        |inner - (r^2 + pad - l2)| <= eps (3 (r^2 + pad) + 36.1 B^2)  (rounding |u|^2 - M, three
-//          fused steps of magnitude <= r^2 + pad + 8 B^2, and 16.02 eps B^2 from rounding u, v);
-//        fbn^2 >= bp^2 - 2 |bp| 26.7 eps B >= bp^2 - 151.3 eps B^2  (|bp| <= 2.832 B).
-//      Hence g >= D + pad - eps (3 (r^2 + pad) + 187.4 B^2) and pad = 2^-21 r^2 + 200 eps B^2 makes
-//      g >= 0 whenever D >= 0 (the final rounding keeps the sign); inner < 0 implies
-//      l2 - r^2 > 5 eps r^2 + 163 eps B^2 > 0.  Those slacks exceed the f64 rounding of the
-//      reference's own delta and roots (<= 2^-50 (B^2 + r^2)) by many orders of magnitude.
-//      A circle is kept iff g >= 0 and not (fbn >= 0 and inner < 0).
+//      u = o - m, v = c - m (|u_i|, |v_i| <= B).  The reference reports no hit when its
+//      delta / 4 = D = (d.oc)^2 - |oc|^2 + r^2 is negative.  For a unit direction
+//      |oc|^2 - (d.oc)^2 is the squared cross product, so D = r^2 - X^2 with
+//        X = d x (u - v) = (dx uy - dy ux) + dy vx - dx vy,
+//      the first term per ray, and a circle pair costs three packed operations
+//      (two fused steps for X, one for g = pad + r^2 - X^2) and one v_alignbit each.
+//      With u, v, d rounded to f32 (eps = 2^-24, |d_i| <= 1): the per-ray term, the two
+//      fused steps and the rounded inputs put the computed X within 10.7 eps B of the
+//      true one, and |X| <= 2.83 B, so X_f^2 <= X^2 + 60.8 eps B^2.  A direction with
+//      | |d|^2 - 1 | <= 2^-40 moves D by at most 2^-37 B^2, and the reference's own f64
+//      rounding of delta by less than 2^-48 (B^2 + r^2).  Hence pad = 2^-22 r^2 + 64 eps B^2
+//      makes g >= 0 whenever the reference's delta >= 0 (the final rounding keeps the
+//      sign).  Circles behind the ray pass this test (about half of the candidates on
+//      a dense scene); the exact test drops them.  Testing for them here would cost
+//      three more packed operations per pair on EVERY circle, which is more than the
+//      extra candidates cost in phase 2.
 //      Lanes whose origin or direction lies outside the frame mark every slot.
 //    segment, exact f64: the reference's own three cross products; t = tn/den >= 0
 //      and 0 <= u = un/den <= 1 fail for sure when tn (or un) is not tiny
@@ -125,26 +122,21 @@ RT_DEV bool segment_t(double ox, double oy, double rx, double ry, double ax, dou
 // Inactive lanes run phase 1 with the wave and mark nothing.
 // Per-ray operands of the circle filter, each duplicated into both halves of a packed register.
 struct FilterRay {
-    f32x2 ndx, ndy; // -d
-    f32x2 ke;       // d.u - eb
-    f32x2 ax, ay;   // 2 u
-    f32x2 o2m;      // |u|^2 - M
+    f32x2 ndx, dy; // -d.x, d.y
+    f32x2 kc;      // d x u
 };
 
 RT_DEV FilterRay filter_ray(const SceneDev &S, double ox, double oy, double dx, double dy, bool &in_range)
 {
     const double ux = ox - S.filt_mx, uy = oy - S.filt_my;
-    in_range = __builtin_fabs(ux) <= S.filt_B && __builtin_fabs(uy) <= S.filt_B && dx * dx + dy * dy <= 1.001;
-    const float uxf = (float)ux, uyf = (float)uy, dxf = (float)dx, dyf = (float)dy;
-    const float ke = (float)((dx * ux + dy * uy) - S.filt_eb);
-    const float o2m = (float)(((double)uxf * (double)uxf + (double)uyf * (double)uyf) - S.filt_M);
+    in_range = __builtin_fabs(ux) <= S.filt_B && __builtin_fabs(uy) <= S.filt_B &&
+               __builtin_fabs((dx * dx + dy * dy) - 1.0) <= 0x1.0p-40;
+    const float dxf = (float)dx, dyf = (float)dy;
+    const float kc = (float)(dx * uy - dy * ux);
     FilterRay f;
     f.ndx = f32x2{ -dxf, -dxf };
-    f.ndy = f32x2{ -dyf, -dyf };
-    f.ke = f32x2{ ke, ke };
-    f.ax = f32x2{ 2.0f * uxf, 2.0f * uxf };
-    f.ay = f32x2{ 2.0f * uyf, 2.0f * uyf };
-    f.o2m = f32x2{ o2m, o2m };
+    f.dy = f32x2{ dyf, dyf };
+    f.kc = f32x2{ kc, kc };
     return f;
 }
 
@@ -153,21 +145,17 @@ RT_DEV uint32_t filter_word(const SceneDev &S, int lo, int hi, double ox, double
 {
     uint32_t acc = 0;
     const int c_end = hi < S.n_circ ? hi : S.n_circ;
-    // two circles per packed f32 instruction (v_pk_add/fma_f32): the circle count is padded to even
+    // two circles per packed f32 instruction (v_pk_fma_f32): the circle count is padded to even
     // and word boundaries are even, so a pair never straddles a word
 #pragma unroll 4
     for (int s = lo; s < c_end; s += 2) {
         const f32x2 vx = *(K_f32x2)(S.c32x + s);
         const f32x2 vy = *(K_f32x2)(S.c32y + s);
         const f32x2 e = *(K_f32x2)(S.c32e + s);
-        const f32x2 fbn = __builtin_elementwise_fma(f.ndx, vx, __builtin_elementwise_fma(f.ndy, vy, f.ke));
-        const f32x2 inner = __builtin_elementwise_fma(f.ax, vx, __builtin_elementwise_fma(f.ay, vy, e - f.o2m));
-        const f32x2 g = __builtin_elementwise_fma(fbn, fbn, inner);
-        // keep iff g >= 0 and not (surely moving away and origin surely outside)
-        const uint32_t keep0 = ~__float_as_uint(g.x) & (__float_as_uint(fbn.x) | ~__float_as_uint(inner.x));
-        const uint32_t keep1 = ~__float_as_uint(g.y) & (__float_as_uint(fbn.y) | ~__float_as_uint(inner.y));
-        acc = __builtin_amdgcn_alignbit(acc, keep0, 31);
-        acc = __builtin_amdgcn_alignbit(acc, keep1, 31);
+        const f32x2 x = __builtin_elementwise_fma(f.dy, vx, __builtin_elementwise_fma(f.ndx, vy, f.kc)); // d x (u - v)
+        const f32x2 g = __builtin_elementwise_fma(x, -x, e);                                             // padded r^2 - X^2
+        acc = __builtin_amdgcn_alignbit(acc, ~__float_as_uint(g.x), 31); // keep iff g >= 0
+        acc = __builtin_amdgcn_alignbit(acc, ~__float_as_uint(g.y), 31);
     }
     const int s_lo = lo > S.n_circ ? lo : S.n_circ;
 #pragma unroll 2

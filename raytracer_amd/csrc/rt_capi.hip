@@ -86,6 +86,8 @@ struct rt2d_scene {
     rt2d::SceneDev dev{};
     int n_prims = 0;
     double lo[2] = { 0.0, 0.0 }, hi[2] = { 0.0, 0.0 }; // bounding box of every primitive (circles with their radius)
+    int n_circles = 0;                                   // without the slot that pads an odd count
+    mutable double padded_for = -1.0;                    // filt_M the device's c32e array currently holds
 };
 
 struct rt3d_scene {
@@ -376,8 +378,7 @@ int32_t rt2d_scene_create(rt_ctx *ctx, const rt2d_scene_desc *d, rt2d_scene **ou
                 const float vx = (float)(d->circle_cx[i] - fmx), vy = (float)(d->circle_cy[i] - fmy);
                 H(c32x)[k] = vx;
                 H(c32y)[k] = vy;
-                H(c32e)[k] = std::nextafterf(
-                    (float)(r2 * (1.0 + 0x1.0p-21) - ((double)vx * (double)vx + (double)vy * (double)vy)), INFINITY);
+                H(c32e)[k] = INFINITY; // written by pad_radii_kernel before the first launch
             }
             if (ncp > nc) {
                 // padding circle: the filter always drops it (g = -inf) and the exact test can never accept a NaN centre
@@ -425,7 +426,7 @@ int32_t rt2d_scene_create(rt_ctx *ctx, const rt2d_scene_desc *d, rt2d_scene **ou
         S.n_circ = ncp; S.n_seg = ns; S.n_obj = no; S.pad_ = 0;
         S.c32x = c32x; S.c32y = c32y; S.c32e = c32e;
         S.filt_mx = fmx; S.filt_my = fmy;
-        S.filt_B = 0.0; S.filt_eb = 0.0; S.filt_M = 0.0; // set per launch by filter_frame
+        S.filt_B = 0.0; S.filt_M = 0.0; // set per launch by filter_frame
         S.ior = iort; S.inv_ior = inv_iort;
         S.ccx = ccx; S.ccy = ccy; S.cr2 = cr2;
         S.sax = sax; S.say = say; S.ssx = ssx; S.ssy = ssy; S.snx = snx; S.sny = sny;
@@ -440,6 +441,7 @@ int32_t rt2d_scene_create(rt_ctx *ctx, const rt2d_scene_desc *d, rt2d_scene **ou
     if (!sc) return fail(RT_E_OOM, "host allocation failed");
     sc->ctx = ctx;
     sc->n_prims = P;
+    sc->n_circles = nc;
     sc->lo[0] = blo[0]; sc->lo[1] = blo[1]; sc->hi[0] = bhi[0]; sc->hi[1] = bhi[1];
     hipError_t e = hipMalloc(&sc->blob, bytes);
     if (e != hipSuccess) {
@@ -494,7 +496,7 @@ int32_t check_params2d(const rt2d_render_params *p)
 // box [lo, hi] of the launch's first ray origins (every later origin is a hit point, inside the scene's box).
 // The frame is capped at 4x the scene's own half extent: the filter's padding grows with the square of the
 // frame, and origins beyond it take the unfiltered path.
-rt2d::SceneDev filter_frame(const rt2d_scene *scene, const double lo[2], const double hi[2])
+int32_t filter_frame(rt_ctx *ctx, const rt2d_scene *scene, const double lo[2], const double hi[2], rt2d::SceneDev *out)
 {
     rt2d::SceneDev S = scene->dev;
     double half = 0.0, want = 0.0;
@@ -506,9 +508,16 @@ rt2d::SceneDev filter_frame(const rt2d_scene *scene, const double lo[2], const d
     half = std::max(half, 0x1.0p-300);
     const double B = std::min(std::max(half, want), 4.0 * half) * (1.0 + 0x1.0p-20);
     S.filt_B = B;
-    S.filt_eb = 0x1.0p-20 * B;
-    S.filt_M = 200.0 * 0x1.0p-24 * B * B;
-    return S;
+    S.filt_M = 64.0 * 0x1.0p-24 * B * B;
+    if (scene->padded_for != S.filt_M && scene->n_circles > 0) {
+        // the padded radii live in the scene's blob: launches on one scene are ordered on the context's stream
+        hipLaunchKernelGGL(rtk::pad_radii_kernel, dim3((unsigned)((scene->n_circles + rtk::BLOCK - 1) / rtk::BLOCK)), dim3(rtk::BLOCK),
+                           0, ctx->stream, S.cr2, scene->n_circles, S.filt_M, const_cast<float *>(S.c32e));
+        HIP_TRY(hipGetLastError());
+        scene->padded_for = S.filt_M;
+    }
+    *out = S;
+    return RT_OK;
 }
 
 int32_t launch_render2d(rt_ctx *ctx, const rt2d_scene *scene, const rt2d_render_params *p, int list_mode, int64_t n_list,
@@ -524,7 +533,7 @@ int32_t launch_render2d(rt_ctx *ctx, const rt2d_scene *scene, const rt2d_render_
             lo[0] = (lo_px[0] - 0.5) * p->px_to_world; lo[1] = (lo_px[1] - 0.5) * p->px_to_world;
             hi[0] = (hi_px[0] + 0.5) * p->px_to_world; hi[1] = (hi_px[1] + 0.5) * p->px_to_world;
         }
-        A.S = filter_frame(scene, lo, hi);
+        if (int32_t rc = filter_frame(ctx, scene, lo, hi, &A.S)) return rc;
     }
     A.width = p->width; A.height = p->height; A.spp = p->spp; A.lambda_samples = p->lambda_samples;
     A.recursion_limit = p->recursion_limit; A.sample_offset = p->sample_offset;
@@ -741,12 +750,14 @@ int32_t rt2d_trace_batch(rt_ctx *ctx, const rt2d_scene *scene, int64_t n, const 
     HIP_TRY(hipMemcpyAsync(d_dx, dx, nb8, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipMemcpyAsync(d_dy, dy, nb8, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipMemcpyAsync(d_li, lambda_idx, nb4, hipMemcpyHostToDevice, ctx->stream));
+    rt2d::SceneDev frame;
+    if (int32_t rc = filter_frame(ctx, scene, lo_o, hi_o, &frame)) return rc;
     std::pair<hipEvent_t, hipEvent_t> ev;
     if (int32_t rc = fold_events(ctx, 256)) return rc;
     if (int32_t rc = event_pair(ctx, &ev)) return rc;
     HIP_TRY(hipEventRecord(ev.first, ctx->stream));
     const unsigned blocks = (unsigned)((n + rtk::BLOCK - 1) / rtk::BLOCK);
-    hipLaunchKernelGGL(rtk::trace_batch2d_kernel, dim3(blocks), dim3(rtk::BLOCK), 0, ctx->stream, filter_frame(scene, lo_o, hi_o), n, d_ox, d_oy, d_dx,
+    hipLaunchKernelGGL(rtk::trace_batch2d_kernel, dim3(blocks), dim3(rtk::BLOCK), 0, ctx->stream, frame, n, d_ox, d_oy, d_dx,
                        d_dy, d_li, depth, (uint32_t)seed, (uint32_t)(seed >> 32), d_rad, d_fp, d_ft, d_nb, ctx->d_rays);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(ev.second, ctx->stream));
