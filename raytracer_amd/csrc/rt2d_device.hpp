@@ -50,6 +50,20 @@ struct SceneDev {
     const float *spectra;
 };
 
+// The kernels read the scene where it arrives - in the kernel-argument segment, constant address space - through
+// this pointer, field by field at the point of use.  Copied into a by-value struct every field would be loaded
+// into a scalar register at kernel entry and stay live over the whole trace loop; there are more of them than
+// scalar registers, and each overflow costs a vector instruction (v_readlane) at every use.
+typedef const SceneDev __attribute__((address_space(4))) *SceneK;
+
+// Cuts the compiler's view of where a scene pointer came from, so the loads behind it are issued after this
+// point (per phase of the loop) instead of being hoisted to the top and kept in registers across the phases.
+RT_DEV SceneK fresh(SceneK s)
+{
+    asm volatile("" : "+s"(s));
+    return s;
+}
+
 struct Hit {
     double t;
     int32_t slot; // < 0: miss
@@ -126,10 +140,10 @@ struct FilterRay {
     f32x2 kc;      // d x u
 };
 
-RT_DEV FilterRay filter_ray(const SceneDev &S, double ox, double oy, double dx, double dy, bool &in_range)
+RT_DEV FilterRay filter_ray(SceneK S, double ox, double oy, double dx, double dy, bool &in_range)
 {
-    const double ux = ox - S.filt_mx, uy = oy - S.filt_my;
-    in_range = __builtin_fabs(ux) <= S.filt_B && __builtin_fabs(uy) <= S.filt_B &&
+    const double ux = ox - S->filt_mx, uy = oy - S->filt_my;
+    in_range = __builtin_fabs(ux) <= S->filt_B && __builtin_fabs(uy) <= S->filt_B &&
                __builtin_fabs((dx * dx + dy * dy) - 1.0) <= 0x1.0p-40;
     const float dxf = (float)dx, dyf = (float)dy;
     const float kc = (float)(dx * uy - dy * ux);
@@ -140,28 +154,28 @@ RT_DEV FilterRay filter_ray(const SceneDev &S, double ox, double oy, double dx, 
     return f;
 }
 
-RT_DEV uint32_t filter_word(const SceneDev &S, int lo, int hi, double ox, double oy, double dx, double dy, const FilterRay &f,
+RT_DEV uint32_t filter_word(SceneK S, int lo, int hi, double ox, double oy, double dx, double dy, const FilterRay &f,
                             uint32_t force)
 {
     uint32_t acc = 0;
-    const int c_end = hi < S.n_circ ? hi : S.n_circ;
+    const int c_end = hi < S->n_circ ? hi : S->n_circ;
     // two circles per packed f32 instruction (v_pk_fma_f32): the circle count is padded to even
     // and word boundaries are even, so a pair never straddles a word
 #pragma unroll 4
     for (int s = lo; s < c_end; s += 2) {
-        const f32x2 vx = *(K_f32x2)(S.c32x + s);
-        const f32x2 vy = *(K_f32x2)(S.c32y + s);
-        const f32x2 e = *(K_f32x2)(S.c32e + s);
+        const f32x2 vx = *(K_f32x2)(S->c32x + s);
+        const f32x2 vy = *(K_f32x2)(S->c32y + s);
+        const f32x2 e = *(K_f32x2)(S->c32e + s);
         const f32x2 x = __builtin_elementwise_fma(f.dy, vx, __builtin_elementwise_fma(f.ndx, vy, f.kc)); // d x (u - v)
         const f32x2 g = __builtin_elementwise_fma(x, -x, e);                                             // padded r^2 - X^2
         acc = __builtin_amdgcn_alignbit(acc, ~__float_as_uint(g.x), 31); // keep iff g >= 0
         acc = __builtin_amdgcn_alignbit(acc, ~__float_as_uint(g.y), 31);
     }
-    const int s_lo = lo > S.n_circ ? lo : S.n_circ;
+    const int s_lo = lo > S->n_circ ? lo : S->n_circ;
 #pragma unroll 2
     for (int s = s_lo; s < hi; ++s) {
-        const int k = s - S.n_circ;
-        const double ax = ((K_f64)S.sax)[k], ay = ((K_f64)S.say)[k], sx = ((K_f64)S.ssx)[k], sy = ((K_f64)S.ssy)[k];
+        const int k = s - S->n_circ;
+        const double ax = ((K_f64)S->sax)[k], ay = ((K_f64)S->say)[k], sx = ((K_f64)S->ssx)[k], sy = ((K_f64)S->ssy)[k];
         const double den = dx * sy - dy * sx;
         const double qx = ax - ox, qy = ay - oy;
         const double tn = qx * sy - qy * sx;
@@ -200,9 +214,10 @@ struct CoopLds {
 // wave's in-order LDS execution).  The outcome is the minimum over all candidates of (key, pid): the
 // order of evaluation does not matter.  The ring never overflows: fewer than 64 entries are queued when
 // a word (<= 64 entries) is appended, and a round puts back at most what it took.
-RT_DEV Hit nearest_hit(const SceneDev &S, double ox, double oy, double dx, double dy, bool active, CoopLds &L, Prof &prof)
+RT_DEV Hit nearest_hit(SceneK S, double ox, double oy, double dx, double dy, bool active, CoopLds &L, Prof &prof)
 {
-    const int P = S.n_circ + S.n_seg;
+    S = fresh(S);
+    const int P = S->n_circ + S->n_seg;
     const int lane = lane_id();
     // outside the frame the f32 filter is proven for, every slot becomes a candidate (exact tests decide)
     bool in_range;
@@ -259,13 +274,13 @@ RT_DEV Hit nearest_hit(const SceneDev &S, double ox, double oy, double dx, doubl
                 double t = 0.0;
                 int pid = 0;
                 if (on) {
-                    if (s < S.n_circ) {
-                        got = circle_t(rox, roy, rdx, rdy, S.ccx[s], S.ccy[s], S.cr2[s], t);
-                        pid = S.cpid[s];
+                    if (s < S->n_circ) {
+                        got = circle_t(rox, roy, rdx, rdy, S->ccx[s], S->ccy[s], S->cr2[s], t);
+                        pid = S->cpid[s];
                     } else {
-                        const int k = s - S.n_circ;
-                        got = segment_t(rox, roy, rdx, rdy, S.sax[k], S.say[k], S.ssx[k], S.ssy[k], t);
-                        pid = S.spid[k];
+                        const int k = s - S->n_circ;
+                        got = segment_t(rox, roy, rdx, rdy, S->sax[k], S->say[k], S->ssx[k], S->ssy[k], t);
+                        pid = S->spid[k];
                     }
                 }
                 const int64_t key = total_key(t);
@@ -330,30 +345,31 @@ enum ShadeResult { SHADE_CONTINUE = 0, SHADE_DONE = 1, SHADE_DIFFUSE = 2 };
 // its new origin and the surface normal in (dnx, dny); its direction is then drawn
 // by rand_hemisphere_wave, which the whole wave enters together.  Every value is
 // computed with the reference's operations in the reference's order.
-RT_DEV ShadeResult shade(const SceneDev &S, Path &p, const Hit &h, float &value, double &dnx, double &dny, Prof &prof)
+RT_DEV ShadeResult shade(SceneK S, Path &p, const Hit &h, float &value, double &dnx, double &dny, Prof &prof)
 {
     value = 0.0f;
     if (h.slot < 0) return SHADE_DONE;
-    const bool is_circle = h.slot < S.n_circ;
-    const int k = is_circle ? h.slot : h.slot - S.n_circ;
+    S = fresh(S);
+    const bool is_circle = h.slot < S->n_circ;
+    const int k = is_circle ? h.slot : h.slot - S->n_circ;
     const double hx = p.ox + h.t * p.dx, hy = p.oy + h.t * p.dy; // ray.origin + t * ray.dir
     double nx = 0.0, ny = 0.0, cx = 0.0, cy = 0.0;
     bool outside;
     int obj;
     if (is_circle) {
-        cx = S.ccx[k];
-        cy = S.ccy[k];
+        cx = S->ccx[k];
+        cy = S->ccy[k];
         const double ex = cx - p.ox, ey = cy - p.oy; // is_inside(ray.origin), rt_common.rs:75-77
-        outside = !((ex * ex + ey * ey) < S.cr2[k]);
-        obj = S.cobj[k];
+        outside = !((ex * ex + ey * ey) < S->cr2[k]);
+        obj = S->cobj[k];
     } else {
-        nx = S.snx[k];
-        ny = S.sny[k];
+        nx = S->snx[k];
+        ny = S->sny[k];
         outside = (nx * p.dx + ny * p.dy) < 0.0; // rt_common.rs:262
-        obj = S.sobj[k];
+        obj = S->sobj[k];
     }
-    const MatDev m = S.mats[obj];
-    const float sv = S.spectra[m.spectrum * NBINS + p.li];
+    const MatDev m = S->mats[obj];
+    const float sv = S->spectra[m.spectrum * NBINS + p.li];
 
     // (1) classify
     enum { TERM, DIRECTIONAL, DIFFUSE, BEND };
@@ -398,7 +414,7 @@ RT_DEV ShadeResult shade(const SceneDev &S, Path &p, const Hit &h, float &value,
         bool bounce = true;
         if (diel) {
             // glam refract(dir, N, eta); eta = ior leaving (:150-152), 1/ior entering (:247-249)
-            const double eta = outside ? S.inv_ior[m.ior_row * NBINS + p.li] : S.ior[m.ior_row * NBINS + p.li];
+            const double eta = outside ? S->inv_ior[m.ior_row * NBINS + p.li] : S->ior[m.ior_row * NBINS + p.li];
             const double kk = 1.0 - eta * eta * (1.0 - ndi * ndi);
             if (kk >= 0.0) {
                 const double mm = eta * ndi + __builtin_sqrt(kk);
@@ -443,6 +459,10 @@ RT_DEV ShadeResult shade(const SceneDev &S, Path &p, const Hit &h, float &value,
 // a + b = v.x n.x + v.y n.y whenever |a + b| > 2^-40 (|a| + |b|) (the normalised sum differs from
 // (a + b)/|v| by less than 2^-50 (|a| + |b|)/|v|); closer calls evaluate the reference's own expression.
 // The accepted vector is normalised once, as the reference does: v * (1 / sqrt(v.v)).
+// HELPERS[nd] = H | M << 8 with H = 64 / nd helper lanes per direction and M = ceil(2^16 / H), so that
+// lane / H = lane * M >> 16 for lane < 64 (runtime integer division costs ~25 instructions).
+__constant__ const uint32_t HELPERS[65] = { 0x0, 0x40040, 0x80020, 0xC3115, 0x100010, 0x15560C, 0x199A0A, 0x1C7209, 0x200008, 0x249307, 0x2AAB06, 0x333405, 0x333405, 0x400004, 0x400004, 0x400004, 0x400004, 0x555603, 0x555603, 0x555603, 0x555603, 0x555603, 0x800002, 0x800002, 0x800002, 0x800002, 0x800002, 0x800002, 0x800002, 0x800002, 0x800002, 0x800002, 0x800002, 0x1000001, 0x1000001, 0x1000001, 0x1000001, 0x1000001, 0x1000001, 0x1000001, 0x1000001, 0x1000001, 0x1000001, 0x1000001, 0x1000001, 0x1000001, 0x1000001, 0x1000001, 0x1000001, 0x1000001, 0x1000001, 0x1000001, 0x1000001, 0x1000001, 0x1000001, 0x1000001, 0x1000001, 0x1000001, 0x1000001, 0x1000001, 0x1000001, 0x1000001, 0x1000001, 0x1000001, 0x1000001 };
+
 RT_DEV void rand_hemisphere_wave(bool need, double nx, double ny, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t bounce,
                                  uint32_t k0, uint32_t k1, double &rx, double &ry)
 {
@@ -454,19 +474,18 @@ RT_DEV void rand_hemisphere_wave(bool need, double nx, double ny, uint32_t c0, u
     double ovx = 0.0, ovy = 0.0, ol2 = 1.0;
     while (pending != 0) {
         const int nd = __popcll(pending);
-        const int H = 64 / nd; // >= 1, wave-uniform
+        const int H = HELPERS[nd] & 0xFF; // 64 / nd >= 1, wave-uniform
         int tl = lane, toff = 0;
         bool helper = still;
         if (H >= 2) {
-            const int trank = lane / H;
+            const int trank = (lane * (int)(HELPERS[nd] >> 8)) >> 16; // lane / H
             toff = lane - trank * H;
             helper = trank < nd;
-            uint64_t m = pending; // the trank-th set bit of `pending` is the lane this one helps
-            for (int r = 0; m != 0; ++r) {
-                const int b = __ffsll((long long)m) - 1;
-                m &= m - 1;
-                tl = (trank == r) ? b : tl;
-            }
+            // the trank-th set bit of `pending` is the lane this one helps: every pending lane sends its id to
+            // the lane whose index is its rank (forward permute), and helpers fetch it from lane trank
+            // (the other lanes send to lane 63, which nobody reads: nd <= 32 here)
+            const int sent = __builtin_amdgcn_ds_permute((still ? rank_in_mask(pending) : 63) << 2, lane);
+            tl = __builtin_amdgcn_ds_bpermute((trank < nd ? trank : 0) << 2, sent);
         }
         const uint32_t tc0 = __shfl(c0, tl), tc1 = __shfl(c1, tl), tc2 = __shfl(c2, tl);
         const uint32_t tb = __shfl(bounce, tl), tbase = __shfl(base, tl);
