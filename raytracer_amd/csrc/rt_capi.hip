@@ -575,9 +575,15 @@ int32_t launch_render2d(rt_ctx *ctx, const rt2d_scene *scene, const rt2d_render_
         A.chunk = (int32_t)((total + runs - 1) / runs);
         A.n_units = (int32_t)(tiles * ((total + A.chunk - 1) / A.chunk));
     }
-    // persistent waves: enough workgroups to fill every CU at 6 per CU, never more waves than tiles
+    // persistent waves: as many workgroups as can be resident at once, never more waves than units
     const int waves_per_block = rtk::BLOCK / 64;
-    const int64_t blocks = std::min<int64_t>((tiles + waves_per_block - 1) / waves_per_block, (int64_t)std::max(ctx->n_cu, 1) * 6);
+    static int per_cu = 0; // resident workgroups per CU, as the runtime computes it from the kernel's registers and LDS
+    if (per_cu == 0) {
+        int nb = 0;
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, rtk::render2d_kernel, rtk::BLOCK, 0));
+        per_cu = std::max(nb, 1);
+    }
+    const int64_t blocks = std::min<int64_t>(((int64_t)A.n_units + waves_per_block - 1) / waves_per_block, (int64_t)std::max(ctx->n_cu, 1) * per_cu);
     HIP_TRY(hipMemsetAsync(A.tile_counter, 0, sizeof(int32_t), ctx->stream));
     if (list_mode) HIP_TRY(hipMemsetAsync(d_out, 0, sizeof(float) * (size_t)n_list * RT_NBINS, ctx->stream));
     std::pair<hipEvent_t, hipEvent_t> ev;
