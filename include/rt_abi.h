@@ -166,7 +166,10 @@ int32_t rt2d_render(rt_ctx *ctx, const rt2d_scene *scene, const rt2d_render_para
  * [W*H][95]; per-sample term = value / lambda_samples * 95, librt2d_reverse.rs:
  * 102-107); rt2d_resolve divides by total_spp (:109), converts to sRGB
  * (spectrum.rs:242-278) and writes host out_rgb / out_weight (either nullable)
- * and, if d_rgb is non-NULL, device f32 [W*H][3].                             */
+ * and, if d_rgb is non-NULL, device f32 [W*H][3].
+ * d_spectrum must be ordinary device memory of this GPU (hipMalloc, a torch
+ * tensor): samples are added with hardware f32 atomics, which host-pinned or
+ * fine-grained memory does not support.                                       */
 int32_t rt2d_accumulate(rt_ctx *ctx, const rt2d_scene *scene, const rt2d_render_params *params,
                         void *d_spectrum);
 int32_t rt2d_resolve(rt_ctx *ctx, const void *d_spectrum, int32_t width, int32_t height,
