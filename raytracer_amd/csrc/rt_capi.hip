@@ -94,6 +94,7 @@ struct rt3d_scene {
     rt_ctx *ctx = nullptr;
     void *blob = nullptr;
     rt3d::SceneDev dev{};
+    int stack_levels = 1; // depth of the BVH: entries of the per-lane traversal stack
 };
 
 namespace {
@@ -878,6 +879,7 @@ int32_t rt3d_scene_create(rt_ctx *ctx, const rt3d_scene_desc *d, rt3d_scene **ou
     }
     S.n = n; S.width = d->width; S.height = d->height; S.use_bvh = d->use_bvh ? 1 : 0;
 
+    int stack_levels = 1;
     std::vector<BuildSphere> always, tree;
     std::vector<rt3d::BvhNode> nodes;
     if (S.use_bvh && n > 0) {
@@ -899,6 +901,7 @@ int32_t rt3d_scene_create(rt_ctx *ctx, const rt3d_scene_desc *d, rt3d_scene **ou
             bb.nodes.emplace_back();
             bb.build(0, 0, (int)tree.size(), 1);
             if (bb.max_depth > rt3d::BVH_STACK) return fail(RT_E_LIMIT, "BVH deeper than %d levels", rt3d::BVH_STACK);
+            stack_levels = std::max(bb.max_depth, 1);
             nodes.swap(bb.nodes);
             // leaf ranges index the tree list; shift them past the always-tested spheres
             for (auto &nd : nodes) if (nd.count > 0) nd.left += (int)always.size();
@@ -949,6 +952,7 @@ int32_t rt3d_scene_create(rt_ctx *ctx, const rt3d_scene_desc *d, rt3d_scene **ou
         return fail(RT_E_HIP, "scene upload: %s", hipGetErrorString(e));
     }
     sc->dev = S;
+    sc->stack_levels = stack_levels;
     ctx->live_scenes += 1;
     *out = sc;
     return RT_OK;
@@ -986,7 +990,8 @@ int32_t rt3d_accumulate(rt_ctx *ctx, const rt3d_scene *scene, const rt3d_render_
     if (int32_t rc = fold_events(ctx, 256)) return rc;
     if (int32_t rc = event_pair(ctx, &ev)) return rc;
     HIP_TRY(hipEventRecord(ev.first, ctx->stream));
-    hipLaunchKernelGGL(rtk::render3d_kernel, dim3((unsigned)tiles), dim3(rtk::BLOCK), 0, ctx->stream, A);
+    hipLaunchKernelGGL(rtk::render3d_kernel, dim3((unsigned)tiles), dim3(rtk::BLOCK),
+                       sizeof(int32_t) * rtk::BLOCK * (size_t)scene->stack_levels, ctx->stream, A);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(ev.second, ctx->stream));
     ctx->pending.push_back(ev);
@@ -1038,7 +1043,8 @@ int32_t rt3d_trace_batch(rt_ctx *ctx, const rt3d_scene *scene, int64_t n, const 
     if (int32_t rc = event_pair(ctx, &ev)) return rc;
     HIP_TRY(hipEventRecord(ev.first, ctx->stream));
     const unsigned blocks = (unsigned)((n + rtk::BLOCK - 1) / rtk::BLOCK);
-    hipLaunchKernelGGL(rtk::trace_batch3d_kernel, dim3(blocks), dim3(rtk::BLOCK), 0, ctx->stream, scene->dev, n, d_o, d_d,
+    hipLaunchKernelGGL(rtk::trace_batch3d_kernel, dim3(blocks), dim3(rtk::BLOCK),
+                       sizeof(int32_t) * rtk::BLOCK * (size_t)scene->stack_levels, ctx->stream, scene->dev, n, d_o, d_d,
                        bounce_limit, (uint32_t)seed, (uint32_t)(seed >> 32), d_rgb, d_fp, d_ft, d_nb, ctx->d_rays);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(ev.second, ctx->stream));
