@@ -17,17 +17,25 @@
 namespace rt3d {
 using namespace rtd;
 
-// BVH node, 64 B.  Inner node: count == 0, children at `left` and `left + 1`.
-// Leaf: `count` spheres starting at slot `left` (slots are BVH order; `sid`
-// maps a slot back to the caller's sphere index).  Boxes are padded outward on
-// the host by a relative margin far larger than the rounding error of the slab
-// arithmetic, so a sphere hit at distance t always lies inside [tmin, tmax] of
-// every ancestor box as computed here.
+// Host-side build node (median split): box of the node, inner: count == 0 and children at `left`,
+// `left + 1`; leaf: `count` spheres starting at slot `left`.
 struct BvhNode {
     double lo[3], hi[3];
     int32_t left, count;
-    int32_t axis; // split axis of an inner node: the child on the ray's near side is visited first
+    int32_t axis;
     int32_t pad_;
+};
+
+// Traversal node, 64 B, one per inner build node: the boxes of BOTH children in f32 and what each child is.
+// child >= 0: index of an inner node; child < 0: a leaf, ~child = first slot << 2 | count (count <= 2).
+// Slots are BVH leaf order; `sid` maps a slot back to the caller's sphere index.  Boxes are rounded
+// outward to f32 from boxes already padded by 1e-7 x scene scale; the traversal adds a per-ray pad and a
+// relative slack (see box_interval), so a sphere hit at distance t always lies inside [tn, tf] of every
+// ancestor box as computed here.
+struct BvhNode2 {
+    float lo[2][3], hi[2][3];
+    int32_t child[2];
+    int32_t pad_[2];
 };
 
 struct SceneDev {
@@ -36,7 +44,8 @@ struct SceneDev {
     // large for the tree), then BVH leaf order
     const double *cx, *cy, *cz, *r2;
     const int32_t *sid;
-    const BvhNode *nodes;
+    const BvhNode2 *nodes;
+    double box_scale; // largest |coordinate| of a tree box
     double pos[3], p00[3], du[3], dv[3];
 };
 
@@ -126,29 +135,31 @@ RT_DEV void scan_range(const SceneDev &S, int first, int last, double ox, double
     }
 }
 
-// Slab test against a padded box (method of 2d/src/aabb.rs:39-66, three axes):
-// true iff the box may contain a hit with total_cmp key <= best_key.
-RT_DEV bool box_may_hit(const BvhNode &nd, double ox, double oy, double oz, double ix, double iy, double iz,
-                        double t_best, bool have_best)
+// Slab interval of a ray against a child box (method of 2d/src/aabb.rs:39-66, three axes) in f32, made
+// conservative in three steps: (1) the box is rounded outward on the host; (2) the origin enters as
+// ol = o + pad and oh = o - pad with pad = 2^-21 (|o|_inf + scene scale), which exceeds the error of rounding
+// o to f32 plus that of the f32 subtraction (<= 2^-23 |o| + 2^-24 scale), so lo - ol and hi - oh are below /
+// above the true differences; (3) 1/d carries a relative error <= 2^-23 and the product another 2^-24: the
+// bounds are moved apart by 2^-20 |t|.  Returns true iff the padded interval reaches t >= 0; tn is its lower
+// end.  NaN (0 * inf: origin on a slab plane of an axis-parallel ray) is dropped by min/max: conservative.
+RT_DEV bool box_interval(const float lo[3], const float hi[3], const float ol[3], const float oh[3], const float id[3],
+                         float &tn)
 {
-    const double tx1 = (nd.lo[0] - ox) * ix, tx2 = (nd.hi[0] - ox) * ix;
-    double tmin = __builtin_fmin(tx1, tx2), tmax = __builtin_fmax(tx1, tx2);
-    const double ty1 = (nd.lo[1] - oy) * iy, ty2 = (nd.hi[1] - oy) * iy;
-    tmin = __builtin_fmax(__builtin_fmin(ty1, ty2), tmin);
-    tmax = __builtin_fmin(__builtin_fmax(ty1, ty2), tmax);
-    const double tz1 = (nd.lo[2] - oz) * iz, tz2 = (nd.hi[2] - oz) * iz;
-    tmin = __builtin_fmax(__builtin_fmin(tz1, tz2), tmin);
-    tmax = __builtin_fmin(__builtin_fmax(tz1, tz2), tmax);
-    // NaN (0 * inf when the origin lies on a slab plane of an axis-parallel ray)
-    // is dropped by fmin/fmax, which keeps the other operand: conservative.
-    if (!(tmax >= __builtin_fmax(tmin, 0.0))) return false;
-    if (have_best && tmin > t_best) return false; // equal t may still win on index
-    return true;
+    const float tx1 = (lo[0] - ol[0]) * id[0], tx2 = (hi[0] - oh[0]) * id[0];
+    const float ty1 = (lo[1] - ol[1]) * id[1], ty2 = (hi[1] - oh[1]) * id[1];
+    const float tz1 = (lo[2] - ol[2]) * id[2], tz2 = (hi[2] - oh[2]) * id[2];
+    const float tmin = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(tx1, tx2), __builtin_fminf(ty1, ty2)), __builtin_fminf(tz1, tz2));
+    const float tmax = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(tx1, tx2), __builtin_fmaxf(ty1, ty2)), __builtin_fmaxf(tz1, tz2));
+    tn = tmin - __builtin_fabsf(tmin) * 0x1.0p-20f;
+    const float tf = tmax + __builtin_fabsf(tmax) * 0x1.0p-20f;
+    return tf >= __builtin_fmaxf(tn, 0.0f);
 }
 
 constexpr int BVH_STACK = 32;
 
-// `stack` points at this lane's column of an LDS array laid out [level][lane].
+// `stack` points at this lane's column of an LDS array laid out [level][2][lane]: child index and the
+// lower end of its interval (float bits), so that a popped subtree can be dropped without a visit when a
+// nearer hit has been found since it was pushed.
 RT_DEV Hit nearest_hit(const SceneDev &S, double ox, double oy, double oz, double dx, double dy, double dz,
                        bool active, int32_t *stack, int stack_stride)
 {
@@ -163,28 +174,52 @@ RT_DEV Hit nearest_hit(const SceneDev &S, double ox, double oy, double oz, doubl
     }
     scan_range(S, 0, S.n_always, ox, oy, oz, dx, dy, dz, active, best, best_key);
     if (S.n_nodes == 0) return best;
-    const double ix = 1.0 / dx, iy = 1.0 / dy, iz = 1.0 / dz;
+    const float oxf = (float)ox, oyf = (float)oy, ozf = (float)oz;
+    const float pad = (__builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(oxf), __builtin_fabsf(oyf)), __builtin_fabsf(ozf)) + (float)S.box_scale) * 0x1.0p-21f;
+    const float ol[3] = { oxf + pad, oyf + pad, ozf + pad }, oh[3] = { oxf - pad, oyf - pad, ozf - pad };
+    const float id[3] = { 1.0f / (float)dx, 1.0f / (float)dy, 1.0f / (float)dz };
     int sp = 0;
     int node = active ? 0 : -1;
-    while (__any(node >= 0)) {
+    while (__any(node >= 0 || sp > 0)) {
+        int next = -1;
         if (node >= 0) {
-            const BvhNode nd = S.nodes[node];
-            int next = -1;
-            if (box_may_hit(nd, ox, oy, oz, ix, iy, iz, best.t, best.slot >= 0)) {
-                if (nd.count > 0) {
-                    for (int k = 0; k < nd.count; ++k)
-                        consider(S, nd.left + k, ox, oy, oz, dx, dy, dz, best, best_key);
-                } else {
-                    const double da = (nd.axis == 0) ? dx : (nd.axis == 1) ? dy : dz;
-                    const int near = (da < 0.0) ? 1 : 0;
-                    next = nd.left + near;
-                    stack[sp * stack_stride] = nd.left + (1 - near); // depth is validated <= BVH_STACK on the host
-                    ++sp;
+            const BvhNode2 nd = S.nodes[node];
+            float tn0, tn1;
+            bool h0 = box_interval(nd.lo[0], nd.hi[0], ol, oh, id, tn0);
+            bool h1 = box_interval(nd.lo[1], nd.hi[1], ol, oh, id, tn1);
+            // equal t may still win on index: drop a box only when its interval starts beyond the best hit
+            if (best.slot >= 0) {
+                h0 = h0 && !((double)tn0 > best.t);
+                h1 = h1 && !((double)tn1 > best.t);
+            }
+            // leaves first: their hits shorten what the inner children still have to offer
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const bool hc = c == 0 ? h0 : h1;
+                if (hc && nd.child[c] < 0) {
+                    const int enc = ~nd.child[c];
+                    const int first = enc >> 2, cnt = enc & 3;
+                    for (int k = 0; k < cnt; ++k) consider(S, first + k, ox, oy, oz, dx, dy, dz, best, best_key);
                 }
             }
-            if (next < 0 && sp > 0) { --sp; next = stack[sp * stack_stride]; }
-            node = next;
+            const bool i0 = h0 && nd.child[0] >= 0, i1 = h1 && nd.child[1] >= 0;
+            if (i0 && i1) {
+                const bool first0 = tn0 <= tn1;
+                next = first0 ? nd.child[0] : nd.child[1];
+                stack[(2 * sp) * stack_stride] = first0 ? nd.child[1] : nd.child[0]; // depth is validated <= BVH_STACK on the host
+                stack[(2 * sp + 1) * stack_stride] = __float_as_int(first0 ? tn1 : tn0);
+                ++sp;
+            } else if (i0 || i1) {
+                next = i0 ? nd.child[0] : nd.child[1];
+            }
         }
+        if (next < 0 && sp > 0) {
+            --sp;
+            const int cand = stack[(2 * sp) * stack_stride];
+            const float tc = __int_as_float(stack[(2 * sp + 1) * stack_stride]);
+            if (!(best.slot >= 0 && (double)tc > best.t)) next = cand; // else: pop again in the next iteration
+        }
+        node = next;
     }
     return best;
 }

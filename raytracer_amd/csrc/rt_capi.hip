@@ -881,7 +881,8 @@ int32_t rt3d_scene_create(rt_ctx *ctx, const rt3d_scene_desc *d, rt3d_scene **ou
 
     int stack_levels = 1;
     std::vector<BuildSphere> always, tree;
-    std::vector<rt3d::BvhNode> nodes;
+    std::vector<rt3d::BvhNode2> nodes;
+    double box_scale = 1.0;
     if (S.use_bvh && n > 0) {
         std::vector<double> radii((size_t)n);
         for (int i = 0; i < n; ++i) radii[(size_t)i] = std::fabs(d->r[i]);
@@ -893,6 +894,10 @@ int32_t rt3d_scene_create(rt_ctx *ctx, const rt3d_scene_desc *d, rt3d_scene **ou
             if (std::fabs(d->r[i]) > 64.0 * r_med && always.size() < 32) always.push_back(b);
             else tree.push_back(b);
         }
+        if (tree.size() <= 2) { // no tree worth the name: scan them
+            always.insert(always.end(), tree.begin(), tree.end());
+            tree.clear();
+        }
         if (!tree.empty()) {
             double scale = 1.0;
             for (const BuildSphere &b : tree)
@@ -902,21 +907,37 @@ int32_t rt3d_scene_create(rt_ctx *ctx, const rt3d_scene_desc *d, rt3d_scene **ou
             bb.build(0, 0, (int)tree.size(), 1);
             if (bb.max_depth > rt3d::BVH_STACK) return fail(RT_E_LIMIT, "BVH deeper than %d levels", rt3d::BVH_STACK);
             stack_levels = std::max(bb.max_depth, 1);
-            nodes.swap(bb.nodes);
-            // leaf ranges index the tree list; shift them past the always-tested spheres
-            for (auto &nd : nodes) if (nd.count > 0) nd.left += (int)always.size();
+            // traversal nodes: one per build node (leaf entries stay unused), children's boxes rounded outward to f32
+            auto down = [](double v) { float f = (float)v; return ((double)f > v) ? std::nextafterf(f, -INFINITY) : f; };
+            auto up = [](double v) { float f = (float)v; return ((double)f < v) ? std::nextafterf(f, INFINITY) : f; };
+            nodes.assign(bb.nodes.size(), rt3d::BvhNode2{});
+            for (size_t i = 0; i < bb.nodes.size(); ++i) {
+                const rt3d::BvhNode &b = bb.nodes[i];
+                if (b.count > 0) continue;
+                for (int c = 0; c < 2; ++c) {
+                    const rt3d::BvhNode &ch = bb.nodes[(size_t)b.left + (size_t)c];
+                    for (int a = 0; a < 3; ++a) {
+                        nodes[i].lo[c][a] = down(ch.lo[a]);
+                        nodes[i].hi[c][a] = up(ch.hi[a]);
+                        box_scale = std::max(box_scale, std::max(std::fabs(ch.lo[a]), std::fabs(ch.hi[a])));
+                    }
+                    // leaf ranges index the tree list; shift them past the always-tested spheres
+                    nodes[i].child[c] = (ch.count > 0) ? ~(((ch.left + (int)always.size()) << 2) | ch.count) : b.left + c;
+                }
+            }
         }
     } else {
         for (int i = 0; i < n; ++i) tree.push_back(BuildSphere{ { d->cx[i], d->cy[i], d->cz[i] }, d->r[i], i });
     }
     S.n_always = (int)always.size();
     S.n_nodes = (int)nodes.size();
+    S.box_scale = box_scale;
 
     Carver sz{ nullptr };
     auto layout = [&](Carver &c, std::vector<char> *host) {
         double *cx = c.take<double>(n), *cy = c.take<double>(n), *cz = c.take<double>(n), *r2 = c.take<double>(n);
         int32_t *sid = c.take<int32_t>(n);
-        rt3d::BvhNode *nd = c.take<rt3d::BvhNode>(nodes.size());
+        rt3d::BvhNode2 *nd = c.take<rt3d::BvhNode2>(nodes.size());
         if (host) {
             char *hb = host->data();
             auto H = [&](auto *p) { return reinterpret_cast<decltype(p)>(hb + (reinterpret_cast<char *>(p) - c.base)); };
@@ -928,7 +949,7 @@ int32_t rt3d_scene_create(rt_ctx *ctx, const rt3d_scene_desc *d, rt3d_scene **ou
                     H(sid)[k] = b.sid;
                     ++k;
                 }
-            if (!nodes.empty()) memcpy(H(nd), nodes.data(), sizeof(rt3d::BvhNode) * nodes.size());
+            if (!nodes.empty()) memcpy(H(nd), nodes.data(), sizeof(rt3d::BvhNode2) * nodes.size());
         }
         S.cx = cx; S.cy = cy; S.cz = cz; S.r2 = r2; S.sid = sid; S.nodes = nd;
     };
@@ -991,7 +1012,7 @@ int32_t rt3d_accumulate(rt_ctx *ctx, const rt3d_scene *scene, const rt3d_render_
     if (int32_t rc = event_pair(ctx, &ev)) return rc;
     HIP_TRY(hipEventRecord(ev.first, ctx->stream));
     hipLaunchKernelGGL(rtk::render3d_kernel, dim3((unsigned)tiles), dim3(rtk::BLOCK),
-                       sizeof(int32_t) * rtk::BLOCK * (size_t)scene->stack_levels, ctx->stream, A);
+                       2 * sizeof(int32_t) * rtk::BLOCK * (size_t)scene->stack_levels, ctx->stream, A);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(ev.second, ctx->stream));
     ctx->pending.push_back(ev);
@@ -1044,7 +1065,7 @@ int32_t rt3d_trace_batch(rt_ctx *ctx, const rt3d_scene *scene, int64_t n, const 
     HIP_TRY(hipEventRecord(ev.first, ctx->stream));
     const unsigned blocks = (unsigned)((n + rtk::BLOCK - 1) / rtk::BLOCK);
     hipLaunchKernelGGL(rtk::trace_batch3d_kernel, dim3(blocks), dim3(rtk::BLOCK),
-                       sizeof(int32_t) * rtk::BLOCK * (size_t)scene->stack_levels, ctx->stream, scene->dev, n, d_o, d_d,
+                       2 * sizeof(int32_t) * rtk::BLOCK * (size_t)scene->stack_levels, ctx->stream, scene->dev, n, d_o, d_d,
                        bounce_limit, (uint32_t)seed, (uint32_t)(seed >> 32), d_rgb, d_fp, d_ft, d_nb, ctx->d_rays);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(ev.second, ctx->stream));
