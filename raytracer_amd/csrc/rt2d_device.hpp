@@ -30,6 +30,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // timer read, volatile asm) sits between kernel entry and the load, which costs the filter loop 20 %.
 typedef const f32x2 __attribute__((address_space(4))) *K_f32x2;
 typedef const double __attribute__((address_space(4))) *K_f64;
+typedef const float __attribute__((address_space(4))) *K_f32;
 
 // Scene in HBM, struct-of-arrays.  Slot order: circles by ascending pid, then
 // segments by ascending pid.  cr2 = r*r and (ssx, ssy) = b - a are the values the
@@ -154,27 +155,27 @@ RT_DEV FilterRay filter_ray(SceneK S, double ox, double oy, double dx, double dy
     return f;
 }
 
-RT_DEV uint32_t filter_word(SceneK S, int lo, int hi, double ox, double oy, double dx, double dy, const FilterRay &f,
-                            uint32_t force)
+RT_DEV uint32_t filter_word(SceneK S, int n_circ, K_f32 c32x, K_f32 c32y, K_f32 c32e, int lo, int hi, double ox, double oy, double dx,
+                            double dy, const FilterRay &f, uint32_t force)
 {
     uint32_t acc = 0;
-    const int c_end = hi < S->n_circ ? hi : S->n_circ;
+    const int c_end = hi < n_circ ? hi : n_circ;
     // two circles per packed f32 instruction (v_pk_fma_f32): the circle count is padded to even
     // and word boundaries are even, so a pair never straddles a word
 #pragma unroll 4
     for (int s = lo; s < c_end; s += 2) {
-        const f32x2 vx = *(K_f32x2)(S->c32x + s);
-        const f32x2 vy = *(K_f32x2)(S->c32y + s);
-        const f32x2 e = *(K_f32x2)(S->c32e + s);
+        const f32x2 vx = *(K_f32x2)(c32x + s);
+        const f32x2 vy = *(K_f32x2)(c32y + s);
+        const f32x2 e = *(K_f32x2)(c32e + s);
         const f32x2 x = __builtin_elementwise_fma(f.dy, vx, __builtin_elementwise_fma(f.ndx, vy, f.kc)); // d x (u - v)
         const f32x2 g = __builtin_elementwise_fma(x, -x, e);                                             // padded r^2 - X^2
         acc = __builtin_amdgcn_alignbit(acc, ~__float_as_uint(g.x), 31); // keep iff g >= 0
         acc = __builtin_amdgcn_alignbit(acc, ~__float_as_uint(g.y), 31);
     }
-    const int s_lo = lo > S->n_circ ? lo : S->n_circ;
+    const int s_lo = lo > n_circ ? lo : n_circ;
 #pragma unroll 2
     for (int s = s_lo; s < hi; ++s) {
-        const int k = s - S->n_circ;
+        const int k = s - n_circ;
         const double ax = ((K_f64)S->sax)[k], ay = ((K_f64)S->say)[k], sx = ((K_f64)S->ssx)[k], sy = ((K_f64)S->ssy)[k];
         const double den = dx * sy - dy * sx;
         const double qx = ax - ox, qy = ay - oy;
@@ -217,7 +218,10 @@ struct CoopLds {
 RT_DEV Hit nearest_hit(SceneK S, double ox, double oy, double dx, double dy, bool active, CoopLds &L, Prof &prof)
 {
     S = fresh(S);
-    const int P = S->n_circ + S->n_seg;
+    // read once per call: inside the loops below the compiler would fetch them again for every word
+    const int n_circ = S->n_circ;
+    const int P = n_circ + S->n_seg;
+    const K_f32 c32x = (K_f32)S->c32x, c32y = (K_f32)S->c32y, c32e = (K_f32)S->c32e;
     const int lane = lane_id();
     // outside the frame the f32 filter is proven for, every slot becomes a candidate (exact tests decide)
     bool in_range;
@@ -230,7 +234,7 @@ RT_DEV Hit nearest_hit(SceneK S, double ox, double oy, double dx, double dy, boo
         const int hi = (lo + 32 < P) ? lo + 32 : P;
         // bits below the word's last slot are shifted-in zeros; `force` may set them, so mask to the valid slots
         const uint32_t valid = 0xFFFFFFFFu << (32 - (hi - lo));
-        uint32_t mw = filter_word(S, lo, hi, ox, oy, dx, dy, fr, force) & valid;
+        uint32_t mw = filter_word(S, n_circ, c32x, c32y, c32e, lo, hi, ox, oy, dx, dy, fr, force) & valid;
         if (!active) mw = 0u;
         RT_STAMP(prof, 1);
 #ifdef RT_PROF
