@@ -222,6 +222,8 @@ RT_DEV Hit nearest_hit(SceneK S, double ox, double oy, double dx, double dy, boo
     const int n_circ = S->n_circ;
     const int P = n_circ + S->n_seg;
     const K_f32 c32x = (K_f32)S->c32x, c32y = (K_f32)S->c32y, c32e = (K_f32)S->c32e;
+    const double *ccx = S->ccx, *ccy = S->ccy, *cr2 = S->cr2;
+    const int32_t *cpid = S->cpid;
     const int lane = lane_id();
     // outside the frame the f32 filter is proven for, every slot becomes a candidate (exact tests decide)
     bool in_range;
@@ -278,11 +280,11 @@ RT_DEV Hit nearest_hit(SceneK S, double ox, double oy, double dx, double dy, boo
                 double t = 0.0;
                 int pid = 0;
                 if (on) {
-                    if (s < S->n_circ) {
-                        got = circle_t(rox, roy, rdx, rdy, S->ccx[s], S->ccy[s], S->cr2[s], t);
-                        pid = S->cpid[s];
+                    if (s < n_circ) {
+                        got = circle_t(rox, roy, rdx, rdy, ccx[s], ccy[s], cr2[s], t);
+                        pid = cpid[s];
                     } else {
-                        const int k = s - S->n_circ;
+                        const int k = s - n_circ;
                         got = segment_t(rox, roy, rdx, rdy, S->sax[k], S->say[k], S->ssx[k], S->ssy[k], t);
                         pid = S->spid[k];
                     }
