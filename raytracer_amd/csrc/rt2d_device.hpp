@@ -35,6 +35,12 @@ typedef const float __attribute__((address_space(4))) *K_f32;
 // Scene in HBM, struct-of-arrays.  Slot order: circles by ascending pid, then
 // segments by ascending pid.  cr2 = r*r and (ssx, ssy) = b - a are the values the
 // reference recomputes in every hit test (rt_common.rs:83, :244).
+// A circle as the exact test and the shading read it: one 32-byte record, two 16-byte loads from one address.
+struct CircleX {
+    double cx, cy, r2; // r2 = r*r, the value the reference recomputes in every hit test (rt_common.rs:83)
+    int32_t pid, obj;
+};
+
 struct SceneDev {
     int32_t n_circ, n_seg, n_obj, pad_; // n_circ is even: an odd circle count is padded with a circle nothing can hit
     // circles as the f32 filter sees them (see filter_word): c32x/c32y = centre - frame centre (filt_mx, filt_my)
@@ -44,9 +50,9 @@ struct SceneDev {
     // filt_M = 64 * 2^-24 filt_B^2 pads the squared radius
     double filt_mx, filt_my, filt_B, filt_M;
     const double *ior, *inv_ior; // [n_ior][95]: Ior::ior(lambda_i) and its reciprocal (rt_common.rs:442-450)
-    const double *ccx, *ccy, *cr2;
+    const CircleX *cex;
     const double *sax, *say, *ssx, *ssy, *snx, *sny;
-    const int32_t *cobj, *cpid, *sobj, *spid;
+    const int32_t *sobj, *spid;
     const MatDev *mats;
     const float *spectra;
 };
@@ -222,8 +228,7 @@ RT_DEV Hit nearest_hit(SceneK S, double ox, double oy, double dx, double dy, boo
     const int n_circ = S->n_circ;
     const int P = n_circ + S->n_seg;
     const K_f32 c32x = (K_f32)S->c32x, c32y = (K_f32)S->c32y, c32e = (K_f32)S->c32e;
-    const double *ccx = S->ccx, *ccy = S->ccy, *cr2 = S->cr2;
-    const int32_t *cpid = S->cpid;
+    const CircleX *cex = S->cex;
     const int lane = lane_id();
     // outside the frame the f32 filter is proven for, every slot becomes a candidate (exact tests decide)
     bool in_range;
@@ -281,8 +286,9 @@ RT_DEV Hit nearest_hit(SceneK S, double ox, double oy, double dx, double dy, boo
                 int pid = 0;
                 if (on) {
                     if (s < n_circ) {
-                        got = circle_t(rox, roy, rdx, rdy, ccx[s], ccy[s], cr2[s], t);
-                        pid = cpid[s];
+                        const CircleX c = cex[s];
+                        got = circle_t(rox, roy, rdx, rdy, c.cx, c.cy, c.r2, t);
+                        pid = c.pid;
                     } else {
                         const int k = s - n_circ;
                         got = segment_t(rox, roy, rdx, rdy, S->sax[k], S->say[k], S->ssx[k], S->ssy[k], t);
@@ -363,11 +369,12 @@ RT_DEV ShadeResult shade(SceneK S, Path &p, const Hit &h, float &value, double &
     bool outside;
     int obj;
     if (is_circle) {
-        cx = S->ccx[k];
-        cy = S->ccy[k];
+        const CircleX c = S->cex[k];
+        cx = c.cx;
+        cy = c.cy;
         const double ex = cx - p.ox, ey = cy - p.oy; // is_inside(ray.origin), rt_common.rs:75-77
-        outside = !((ex * ex + ey * ey) < S->cr2[k]);
-        obj = S->cobj[k];
+        outside = !((ex * ex + ey * ey) < c.r2);
+        obj = c.obj;
     } else {
         nx = S->snx[k];
         ny = S->sny[k];

@@ -359,10 +359,10 @@ int32_t rt2d_scene_create(rt_ctx *ctx, const rt2d_scene_desc *d, rt2d_scene **ou
     auto layout = [&](Carver &c, rt2d::SceneDev &S, std::vector<char> *host) {
         float *c32x = c.take<float>(ncp), *c32y = c.take<float>(ncp), *c32e = c.take<float>(ncp);
         double *iort = c.take<double>((size_t)nior * RT_NBINS), *inv_iort = c.take<double>((size_t)nior * RT_NBINS);
-        double *ccx = c.take<double>(ncp), *ccy = c.take<double>(ncp), *cr2 = c.take<double>(ncp);
+        rt2d::CircleX *cex = c.take<rt2d::CircleX>(ncp);
         double *sax = c.take<double>(ns), *say = c.take<double>(ns), *ssx = c.take<double>(ns), *ssy = c.take<double>(ns);
         double *snx = c.take<double>(ns), *sny = c.take<double>(ns);
-        int32_t *cobj = c.take<int32_t>(ncp), *cpid = c.take<int32_t>(ncp), *sobj = c.take<int32_t>(ns), *spid = c.take<int32_t>(ns);
+        int32_t *sobj = c.take<int32_t>(ns), *spid = c.take<int32_t>(ns);
         rt2d::MatDev *mats = c.take<rt2d::MatDev>(no);
         float *spectra = c.take<float>((size_t)nsp * RT_NBINS);
         if (host) {
@@ -371,11 +371,7 @@ int32_t rt2d_scene_create(rt_ctx *ctx, const rt2d_scene_desc *d, rt2d_scene **ou
             for (int k = 0; k < nc; ++k) {
                 const int i = corder[(size_t)k];
                 const double r2 = d->circle_r[i] * d->circle_r[i]; // r.powi(2), rt_common.rs:76,83
-                H(ccx)[k] = d->circle_cx[i];
-                H(ccy)[k] = d->circle_cy[i];
-                H(cr2)[k] = r2;
-                H(cobj)[k] = d->circle_obj[i];
-                H(cpid)[k] = d->circle_pid[i];
+                H(cex)[k] = rt2d::CircleX{ d->circle_cx[i], d->circle_cy[i], r2, d->circle_pid[i], d->circle_obj[i] };
                 const float vx = (float)(d->circle_cx[i] - fmx), vy = (float)(d->circle_cy[i] - fmy);
                 H(c32x)[k] = vx;
                 H(c32y)[k] = vy;
@@ -384,8 +380,7 @@ int32_t rt2d_scene_create(rt_ctx *ctx, const rt2d_scene_desc *d, rt2d_scene **ou
             if (ncp > nc) {
                 // padding circle: the filter always drops it (g = -inf) and the exact test can never accept a NaN centre
                 H(c32x)[nc] = 0.0f; H(c32y)[nc] = 0.0f; H(c32e)[nc] = -INFINITY;
-                H(ccx)[nc] = NAN; H(ccy)[nc] = NAN; H(cr2)[nc] = 0.0;
-                H(cobj)[nc] = 0; H(cpid)[nc] = 0x7fffffff;
+                H(cex)[nc] = rt2d::CircleX{ NAN, NAN, 0.0, 0x7fffffff, 0 };
             }
             for (int k = 0; k < nior; ++k)
                 for (int b = 0; b < RT_NBINS; ++b) {
@@ -429,9 +424,9 @@ int32_t rt2d_scene_create(rt_ctx *ctx, const rt2d_scene_desc *d, rt2d_scene **ou
         S.filt_mx = fmx; S.filt_my = fmy;
         S.filt_B = 0.0; S.filt_M = 0.0; // set per launch by filter_frame
         S.ior = iort; S.inv_ior = inv_iort;
-        S.ccx = ccx; S.ccy = ccy; S.cr2 = cr2;
+        S.cex = cex;
         S.sax = sax; S.say = say; S.ssx = ssx; S.ssy = ssy; S.snx = snx; S.sny = sny;
-        S.cobj = cobj; S.cpid = cpid; S.sobj = sobj; S.spid = spid;
+        S.sobj = sobj; S.spid = spid;
         S.mats = mats; S.spectra = spectra;
     };
     rt2d::SceneDev tmp{};
@@ -513,7 +508,7 @@ int32_t filter_frame(rt_ctx *ctx, const rt2d_scene *scene, const double lo[2], c
     if (scene->padded_for != S.filt_M && scene->n_circles > 0) {
         // the padded radii live in the scene's blob: launches on one scene are ordered on the context's stream
         hipLaunchKernelGGL(rtk::pad_radii_kernel, dim3((unsigned)((scene->n_circles + rtk::BLOCK - 1) / rtk::BLOCK)), dim3(rtk::BLOCK),
-                           0, ctx->stream, S.cr2, scene->n_circles, S.filt_M, const_cast<float *>(S.c32e));
+                           0, ctx->stream, S.cex, scene->n_circles, S.filt_M, const_cast<float *>(S.c32e));
         HIP_TRY(hipGetLastError());
         scene->padded_for = S.filt_M;
     }
