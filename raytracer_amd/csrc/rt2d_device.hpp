@@ -31,14 +31,22 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef const f32x2 __attribute__((address_space(4))) *K_f32x2;
 typedef const double __attribute__((address_space(4))) *K_f64;
 typedef const float __attribute__((address_space(4))) *K_f32;
+struct SegX;
+typedef const SegX __attribute__((address_space(4))) *K_SegX;
 
-// Scene in HBM, struct-of-arrays.  Slot order: circles by ascending pid, then
-// segments by ascending pid.  cr2 = r*r and (ssx, ssy) = b - a are the values the
-// reference recomputes in every hit test (rt_common.rs:83, :244).
+// Scene in HBM.  Slot order: circles by ascending pid, then segments by ascending pid.
 // A circle as the exact test and the shading read it: one 32-byte record, two 16-byte loads from one address.
 struct CircleX {
     double cx, cy, r2; // r2 = r*r, the value the reference recomputes in every hit test (rt_common.rs:83)
     int32_t pid, obj;
+};
+
+// A segment, 64 bytes: a, s = b - a (the value the reference recomputes in every hit test, rt_common.rs:244),
+// the stored normal, ids.
+struct SegX {
+    double ax, ay, sx, sy, nx, ny;
+    int32_t pid, obj;
+    double pad_;
 };
 
 struct SceneDev {
@@ -51,8 +59,7 @@ struct SceneDev {
     double filt_mx, filt_my, filt_B, filt_M;
     const double *ior, *inv_ior; // [n_ior][95]: Ior::ior(lambda_i) and its reciprocal (rt_common.rs:442-450)
     const CircleX *cex;
-    const double *sax, *say, *ssx, *ssy, *snx, *sny;
-    const int32_t *sobj, *spid;
+    const SegX *sex;
     const MatDev *mats;
     const float *spectra;
 };
@@ -161,7 +168,7 @@ RT_DEV FilterRay filter_ray(SceneK S, double ox, double oy, double dx, double dy
     return f;
 }
 
-RT_DEV uint32_t filter_word(SceneK S, int n_circ, K_f32 c32x, K_f32 c32y, K_f32 c32e, int lo, int hi, double ox, double oy, double dx,
+RT_DEV uint32_t filter_word(int n_circ, K_f32 c32x, K_f32 c32y, K_f32 c32e, K_SegX sex, int lo, int hi, double ox, double oy, double dx,
                             double dy, const FilterRay &f, uint32_t force)
 {
     uint32_t acc = 0;
@@ -182,7 +189,8 @@ RT_DEV uint32_t filter_word(SceneK S, int n_circ, K_f32 c32x, K_f32 c32y, K_f32 
 #pragma unroll 2
     for (int s = s_lo; s < hi; ++s) {
         const int k = s - n_circ;
-        const double ax = ((K_f64)S->sax)[k], ay = ((K_f64)S->say)[k], sx = ((K_f64)S->ssx)[k], sy = ((K_f64)S->ssy)[k];
+        const K_SegX g = sex + k;
+        const double ax = g->ax, ay = g->ay, sx = g->sx, sy = g->sy;
         const double den = dx * sy - dy * sx;
         const double qx = ax - ox, qy = ay - oy;
         const double tn = qx * sy - qy * sx;
@@ -229,6 +237,7 @@ RT_DEV Hit nearest_hit(SceneK S, double ox, double oy, double dx, double dy, boo
     const int P = n_circ + S->n_seg;
     const K_f32 c32x = (K_f32)S->c32x, c32y = (K_f32)S->c32y, c32e = (K_f32)S->c32e;
     const CircleX *cex = S->cex;
+    const SegX *sex = S->sex;
     const int lane = lane_id();
     // outside the frame the f32 filter is proven for, every slot becomes a candidate (exact tests decide)
     bool in_range;
@@ -241,7 +250,7 @@ RT_DEV Hit nearest_hit(SceneK S, double ox, double oy, double dx, double dy, boo
         const int hi = (lo + 32 < P) ? lo + 32 : P;
         // bits below the word's last slot are shifted-in zeros; `force` may set them, so mask to the valid slots
         const uint32_t valid = 0xFFFFFFFFu << (32 - (hi - lo));
-        uint32_t mw = filter_word(S, n_circ, c32x, c32y, c32e, lo, hi, ox, oy, dx, dy, fr, force) & valid;
+        uint32_t mw = filter_word(n_circ, c32x, c32y, c32e, (K_SegX)sex, lo, hi, ox, oy, dx, dy, fr, force) & valid;
         if (!active) mw = 0u;
         RT_STAMP(prof, 1);
 #ifdef RT_PROF
@@ -291,8 +300,9 @@ RT_DEV Hit nearest_hit(SceneK S, double ox, double oy, double dx, double dy, boo
                         pid = c.pid;
                     } else {
                         const int k = s - n_circ;
-                        got = segment_t(rox, roy, rdx, rdy, S->sax[k], S->say[k], S->ssx[k], S->ssy[k], t);
-                        pid = S->spid[k];
+                        const SegX g = sex[k];
+                        got = segment_t(rox, roy, rdx, rdy, g.ax, g.ay, g.sx, g.sy, t);
+                        pid = g.pid;
                     }
                 }
                 const int64_t key = total_key(t);
@@ -376,10 +386,11 @@ RT_DEV ShadeResult shade(SceneK S, Path &p, const Hit &h, float &value, double &
         outside = !((ex * ex + ey * ey) < c.r2);
         obj = c.obj;
     } else {
-        nx = S->snx[k];
-        ny = S->sny[k];
+        const SegX *g = S->sex + k;
+        nx = g->nx;
+        ny = g->ny;
         outside = (nx * p.dx + ny * p.dy) < 0.0; // rt_common.rs:262
-        obj = S->sobj[k];
+        obj = g->obj;
     }
     const MatDev m = S->mats[obj];
     const float sv = S->spectra[m.spectrum * NBINS + p.li];

@@ -360,9 +360,7 @@ int32_t rt2d_scene_create(rt_ctx *ctx, const rt2d_scene_desc *d, rt2d_scene **ou
         float *c32x = c.take<float>(ncp), *c32y = c.take<float>(ncp), *c32e = c.take<float>(ncp);
         double *iort = c.take<double>((size_t)nior * RT_NBINS), *inv_iort = c.take<double>((size_t)nior * RT_NBINS);
         rt2d::CircleX *cex = c.take<rt2d::CircleX>(ncp);
-        double *sax = c.take<double>(ns), *say = c.take<double>(ns), *ssx = c.take<double>(ns), *ssy = c.take<double>(ns);
-        double *snx = c.take<double>(ns), *sny = c.take<double>(ns);
-        int32_t *sobj = c.take<int32_t>(ns), *spid = c.take<int32_t>(ns);
+        rt2d::SegX *sex = c.take<rt2d::SegX>(ns);
         rt2d::MatDev *mats = c.take<rt2d::MatDev>(no);
         float *spectra = c.take<float>((size_t)nsp * RT_NBINS);
         if (host) {
@@ -392,14 +390,9 @@ int32_t rt2d_scene_create(rt_ctx *ctx, const rt2d_scene_desc *d, rt2d_scene **ou
                 }
             for (int k = 0; k < ns; ++k) {
                 const int i = sorder[(size_t)k];
-                H(sax)[k] = d->seg_ax[i];
-                H(say)[k] = d->seg_ay[i];
-                H(ssx)[k] = d->seg_bx[i] - d->seg_ax[i]; // s = b - a, rt_common.rs:244
-                H(ssy)[k] = d->seg_by[i] - d->seg_ay[i];
-                H(snx)[k] = d->seg_nx[i];
-                H(sny)[k] = d->seg_ny[i];
-                H(sobj)[k] = d->seg_obj[i];
-                H(spid)[k] = d->seg_pid[i];
+                // s = b - a, rt_common.rs:244
+                H(sex)[k] = rt2d::SegX{ d->seg_ax[i], d->seg_ay[i], d->seg_bx[i] - d->seg_ax[i], d->seg_by[i] - d->seg_ay[i],
+                                        d->seg_nx[i], d->seg_ny[i], d->seg_pid[i], d->seg_obj[i], 0.0 };
             }
             for (int i = 0; i < no; ++i) {
                 const rt2d_material &m = d->materials[i];
@@ -425,8 +418,7 @@ int32_t rt2d_scene_create(rt_ctx *ctx, const rt2d_scene_desc *d, rt2d_scene **ou
         S.filt_B = 0.0; S.filt_M = 0.0; // set per launch by filter_frame
         S.ior = iort; S.inv_ior = inv_iort;
         S.cex = cex;
-        S.sax = sax; S.say = say; S.ssx = ssx; S.ssy = ssy; S.snx = snx; S.sny = sny;
-        S.sobj = sobj; S.spid = spid;
+        S.sex = sex;
         S.mats = mats; S.spectra = spectra;
     };
     rt2d::SceneDev tmp{};
