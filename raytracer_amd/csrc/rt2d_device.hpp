@@ -33,6 +33,11 @@ typedef const double __attribute__((address_space(4))) *K_f64;
 typedef const float __attribute__((address_space(4))) *K_f32;
 struct SegX;
 typedef const SegX __attribute__((address_space(4))) *K_SegX;
+// A segment as the f32 filter reads it (32 bytes, one scalar load): s = b - a, cs = A x s and A = a - frame centre.
+struct Seg32 { float sx, sy, cs, ax, ay, pad_[3]; };
+typedef const Seg32 __attribute__((address_space(4))) *K_Seg32;
+// Error bounds of the segment filter for one launch (see filter_word).
+struct SegBounds { float ed, et, eu, ew, euew, eted; };
 
 // Scene in HBM.  Slot order: circles by ascending pid, then segments by ascending pid.
 // A circle as the exact test and the shading read it: one 32-byte record, two 16-byte loads from one address.
@@ -60,6 +65,8 @@ struct SceneDev {
     const double *ior, *inv_ior; // [n_ior][95]: Ior::ior(lambda_i) and its reciprocal (rt_common.rs:442-450)
     const CircleX *cex;
     const SegX *sex;
+    const Seg32 *seg32;
+    SegBounds seg_bounds; // set per launch with the frame
     const MatDev *mats;
     const float *spectra;
 };
@@ -139,11 +146,19 @@ RT_DEV bool segment_t(double ox, double oy, double rx, double ry, double ax, dou
 //      three more packed operations per pair on EVERY circle, which is more than the
 //      extra candidates cost in phase 2.
 //      Lanes whose origin or direction lies outside the frame mark every slot.
-//    segment, exact f64: the reference's own three cross products; t = tn/den >= 0
-//      and 0 <= u = un/den <= 1 fail for sure when tn (or un) is not tiny
-//      (|.| >= 2^-900) and differs in sign from den, or when |un| exceeds |den| by
-//      more than 2^-20 relative; scene and ray magnitudes are validated so
-//      |den| <= 2^62 and such a quotient cannot round to -0.0.
+//    segment, f32 with fused ops, same frame (U = o - m, A = a - m, s = b - a, |s_i| <= S):
+//      the reference accepts iff t = tn / den >= 0 and 0 <= u = un / den <= 1 with
+//        den = d x s,   tn = (A - U) x s = (A x s) - U x s,   un = (A - U) x d = A x d - (U x d),
+//      (A x s) per segment and (U x d) per ray.  0 <= u <= 1 is "un lies between 0 and den", i.e.
+//      Q = un (un - den) <= 0 whatever the sign of den, and t >= 0 is P = tn den >= 0.  A segment
+//      is dropped when Q > 0 or P < 0 SURELY.  Absolute errors of the f32 values (eps = 2^-24,
+//      |d_i| <= 1.0005; rounding of the inputs, of the per-ray / per-segment terms and of each
+//      fused step): |den| 7.1 eps S, |tn| 13.1 eps B S, |un| 10.7 eps B, |un - den| 15 eps B + 10.1 eps S.
+//      With the bounds Ed = 12 eps S, Et = 16 eps B S, Eu = 12 eps B, Ew = 20 eps (B + S) (which also
+//      absorb the rounding of the products) a product x y of values known to within Ex, Ey lies
+//      within |x| Ey + |y| Ex + Ex Ey of the true one; Q and P are compared against that.  The
+//      reference's own f64 rounding (and its -0.0 from an underflowing quotient) is many orders of
+//      magnitude inside these margins.  13 f32 operations per segment.
 //  phase 2 (marked slots only, shared out over the wave's lanes, see nearest_hit):
 //    the exact test in the reference's operation order, then (total_cmp key, pid)
 //    lexicographic minimum = "first minimum in scan order" (librt2d_reverse.rs:139).
@@ -152,6 +167,7 @@ RT_DEV bool segment_t(double ox, double oy, double rx, double ry, double ax, dou
 struct FilterRay {
     f32x2 ndx, dy; // -d.x, d.y
     f32x2 kc;      // d x u
+    float ux, uy, rx, ry, nku; // segments: u, d and -(u x d)
 };
 
 RT_DEV FilterRay filter_ray(SceneK S, double ox, double oy, double dx, double dy, bool &in_range)
@@ -165,10 +181,12 @@ RT_DEV FilterRay filter_ray(SceneK S, double ox, double oy, double dx, double dy
     f.ndx = f32x2{ -dxf, -dxf };
     f.dy = f32x2{ dyf, dyf };
     f.kc = f32x2{ kc, kc };
+    f.ux = (float)ux; f.uy = (float)uy; f.rx = dxf; f.ry = dyf;
+    f.nku = -(float)(ux * dy - uy * dx);
     return f;
 }
 
-RT_DEV uint32_t filter_word(int n_circ, K_f32 c32x, K_f32 c32y, K_f32 c32e, K_SegX sex, int lo, int hi, double ox, double oy, double dx,
+RT_DEV uint32_t filter_word(int n_circ, K_f32 c32x, K_f32 c32y, K_f32 c32e, K_Seg32 seg32, const SegBounds &E, int lo, int hi, double ox, double oy, double dx,
                             double dy, const FilterRay &f, uint32_t force)
 {
     uint32_t acc = 0;
@@ -188,23 +206,17 @@ RT_DEV uint32_t filter_word(int n_circ, K_f32 c32x, K_f32 c32y, K_f32 c32e, K_Se
     const int s_lo = lo > n_circ ? lo : n_circ;
 #pragma unroll 2
     for (int s = s_lo; s < hi; ++s) {
-        const int k = s - n_circ;
-        const K_SegX g = sex + k;
-        const double ax = g->ax, ay = g->ay, sx = g->sx, sy = g->sy;
-        const double den = dx * sy - dy * sx;
-        const double qx = ax - ox, qy = ay - oy;
-        const double tn = qx * sy - qy * sx;
-        const double un = qx * dy - qy * dx;
-        const uint32_t dh = (uint32_t)hi32(den), th = (uint32_t)hi32(tn), uh = (uint32_t)hi32(un);
-        const uint32_t TINY = (1023u - 900u) << 20;
-        // sign-magnitude copies of tn, un with the sign taken relative to den
-        const uint32_t st = ((th ^ dh) & 0x80000000u) | (th & 0x7fffffffu);
-        const uint32_t su = ((uh ^ dh) & 0x80000000u) | (uh & 0x7fffffffu);
-        const uint32_t rej_t = (st - TINY) & st;           // negative and not tiny
-        const uint32_t rej_u0 = (su - TINY) & su;
-        const uint32_t rej_u1 = ((dh & 0x7fffffffu) + 1u) - (uh & 0x7fffffffu); // |un|_hi > |den|_hi + 1
-        const uint32_t rej = rej_t | rej_u0 | rej_u1;
-        acc = __builtin_amdgcn_alignbit(acc, ~rej, 31);
+        const K_Seg32 gp = seg32 + (s - n_circ);
+        const struct { float sx, sy, cs, ax, ay; } g = { gp->sx, gp->sy, gp->cs, gp->ax, gp->ay };
+        const float den = __builtin_fmaf(f.rx, g.sy, -(f.ry * g.sx));
+        const float tn = __builtin_fmaf(f.uy, g.sx, __builtin_fmaf(-f.ux, g.sy, g.cs));
+        const float un = __builtin_fmaf(g.ax, f.ry, __builtin_fmaf(-g.ay, f.rx, f.nku));
+        const float w = un - den;
+        const float eq = __builtin_fmaf(__builtin_fabsf(un), E.ew, __builtin_fmaf(__builtin_fabsf(w), E.eu, E.euew));
+        const float ep = __builtin_fmaf(__builtin_fabsf(tn), E.ed, __builtin_fmaf(__builtin_fabsf(den), E.et, E.eted));
+        const float rq = __builtin_fmaf(-un, w, eq);  // < 0: u surely outside [0, 1]
+        const float rp = __builtin_fmaf(tn, den, ep); // < 0: t surely negative
+        acc = __builtin_amdgcn_alignbit(acc, ~(__float_as_uint(rq) | __float_as_uint(rp)), 31);
     }
     return (acc << (32 - (hi - lo))) | force;
 }
@@ -238,6 +250,8 @@ RT_DEV Hit nearest_hit(SceneK S, double ox, double oy, double dx, double dy, boo
     const K_f32 c32x = (K_f32)S->c32x, c32y = (K_f32)S->c32y, c32e = (K_f32)S->c32e;
     const CircleX *cex = S->cex;
     const SegX *sex = S->sex;
+    const K_Seg32 seg32 = (K_Seg32)S->seg32;
+    const SegBounds E = { S->seg_bounds.ed, S->seg_bounds.et, S->seg_bounds.eu, S->seg_bounds.ew, S->seg_bounds.euew, S->seg_bounds.eted };
     const int lane = lane_id();
     // outside the frame the f32 filter is proven for, every slot becomes a candidate (exact tests decide)
     bool in_range;
@@ -250,7 +264,7 @@ RT_DEV Hit nearest_hit(SceneK S, double ox, double oy, double dx, double dy, boo
         const int hi = (lo + 32 < P) ? lo + 32 : P;
         // bits below the word's last slot are shifted-in zeros; `force` may set them, so mask to the valid slots
         const uint32_t valid = 0xFFFFFFFFu << (32 - (hi - lo));
-        uint32_t mw = filter_word(n_circ, c32x, c32y, c32e, (K_SegX)sex, lo, hi, ox, oy, dx, dy, fr, force) & valid;
+        uint32_t mw = filter_word(n_circ, c32x, c32y, c32e, seg32, E, lo, hi, ox, oy, dx, dy, fr, force) & valid;
         if (!active) mw = 0u;
         RT_STAMP(prof, 1);
 #ifdef RT_PROF

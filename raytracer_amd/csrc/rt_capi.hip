@@ -87,6 +87,7 @@ struct rt2d_scene {
     int n_prims = 0;
     double lo[2] = { 0.0, 0.0 }, hi[2] = { 0.0, 0.0 }; // bounding box of every primitive (circles with their radius)
     int n_circles = 0;                                   // without the slot that pads an odd count
+    double seg_extent = 0.0;                             // largest |b - a| component of a segment
     mutable double padded_for = -1.0;                    // filt_M the device's c32e array currently holds
 };
 
@@ -361,6 +362,7 @@ int32_t rt2d_scene_create(rt_ctx *ctx, const rt2d_scene_desc *d, rt2d_scene **ou
         double *iort = c.take<double>((size_t)nior * RT_NBINS), *inv_iort = c.take<double>((size_t)nior * RT_NBINS);
         rt2d::CircleX *cex = c.take<rt2d::CircleX>(ncp);
         rt2d::SegX *sex = c.take<rt2d::SegX>(ns);
+        rt2d::Seg32 *seg32 = c.take<rt2d::Seg32>(ns);
         rt2d::MatDev *mats = c.take<rt2d::MatDev>(no);
         float *spectra = c.take<float>((size_t)nsp * RT_NBINS);
         if (host) {
@@ -393,6 +395,9 @@ int32_t rt2d_scene_create(rt_ctx *ctx, const rt2d_scene_desc *d, rt2d_scene **ou
                 // s = b - a, rt_common.rs:244
                 H(sex)[k] = rt2d::SegX{ d->seg_ax[i], d->seg_ay[i], d->seg_bx[i] - d->seg_ax[i], d->seg_by[i] - d->seg_ay[i],
                                         d->seg_nx[i], d->seg_ny[i], d->seg_pid[i], d->seg_obj[i], 0.0 };
+                const double Ax = d->seg_ax[i] - fmx, Ay = d->seg_ay[i] - fmy;
+                const double sx = d->seg_bx[i] - d->seg_ax[i], sy = d->seg_by[i] - d->seg_ay[i];
+                H(seg32)[k] = rt2d::Seg32{ (float)sx, (float)sy, (float)(Ax * sy - Ay * sx), (float)Ax, (float)Ay, { 0.0f, 0.0f, 0.0f } };
             }
             for (int i = 0; i < no; ++i) {
                 const rt2d_material &m = d->materials[i];
@@ -419,6 +424,8 @@ int32_t rt2d_scene_create(rt_ctx *ctx, const rt2d_scene_desc *d, rt2d_scene **ou
         S.ior = iort; S.inv_ior = inv_iort;
         S.cex = cex;
         S.sex = sex;
+        S.seg32 = seg32;
+        S.seg_bounds = rt2d::SegBounds{ 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f }; // set per launch by filter_frame
         S.mats = mats; S.spectra = spectra;
     };
     rt2d::SceneDev tmp{};
@@ -430,6 +437,9 @@ int32_t rt2d_scene_create(rt_ctx *ctx, const rt2d_scene_desc *d, rt2d_scene **ou
     sc->ctx = ctx;
     sc->n_prims = P;
     sc->n_circles = nc;
+    sc->seg_extent = 0.0;
+    for (int i = 0; i < ns; ++i)
+        sc->seg_extent = std::max(sc->seg_extent, std::max(std::fabs(d->seg_bx[i] - d->seg_ax[i]), std::fabs(d->seg_by[i] - d->seg_ay[i])));
     sc->lo[0] = blo[0]; sc->lo[1] = blo[1]; sc->hi[0] = bhi[0]; sc->hi[1] = bhi[1];
     hipError_t e = hipMalloc(&sc->blob, bytes);
     if (e != hipSuccess) {
@@ -497,6 +507,13 @@ int32_t filter_frame(rt_ctx *ctx, const rt2d_scene *scene, const double lo[2], c
     const double B = std::min(std::max(half, want), 4.0 * half) * (1.0 + 0x1.0p-20);
     S.filt_B = B;
     S.filt_M = 64.0 * 0x1.0p-24 * B * B;
+    {
+        // bounds of the segment filter (derivation in rt2d_device.hpp), rounded up
+        const double eps = 0x1.0p-24, Sx = std::max(scene->seg_extent, 0x1.0p-300);
+        auto up = [](double v) { return std::nextafterf((float)v, INFINITY); };
+        const double ed = 12.0 * eps * Sx, et = 16.0 * eps * B * Sx, eu = 12.0 * eps * B, ew = 20.0 * eps * (B + Sx);
+        S.seg_bounds = rt2d::SegBounds{ up(ed), up(et), up(eu), up(ew), up(eu * ew * 1.001), up(et * ed * 1.001) };
+    }
     if (scene->padded_for != S.filt_M && scene->n_circles > 0) {
         // the padded radii live in the scene's blob: launches on one scene are ordered on the context's stream
         hipLaunchKernelGGL(rtk::pad_radii_kernel, dim3((unsigned)((scene->n_circles + rtk::BLOCK - 1) / rtk::BLOCK)), dim3(rtk::BLOCK),
