@@ -200,9 +200,12 @@ RT_DEV uint32_t filter_word(int n_circ, K_f32 c32x, K_f32 c32y, K_f32 c32e, K_Se
         const f32x2 e = *(K_f32x2)(c32e + s);
         const f32x2 x = __builtin_elementwise_fma(f.dy, vx, __builtin_elementwise_fma(f.ndx, vy, f.kc)); // d x (u - v)
         const f32x2 g = __builtin_elementwise_fma(x, -x, e);                                             // padded r^2 - X^2
-        acc = __builtin_amdgcn_alignbit(acc, ~__float_as_uint(g.x), 31); // keep iff g >= 0
-        acc = __builtin_amdgcn_alignbit(acc, ~__float_as_uint(g.y), 31);
+        acc = __builtin_amdgcn_alignbit(acc, __float_as_uint(g.x), 31); // collects the sign of g: set = drop
+        acc = __builtin_amdgcn_alignbit(acc, __float_as_uint(g.y), 31);
     }
+    // keep iff g >= 0.  The ones this puts above the bits collected so far are shifted out below: by the end
+    // exactly hi - lo bits have been appended and the word is shifted up by 32 - (hi - lo).
+    acc = ~acc;
     const int s_lo = lo > n_circ ? lo : n_circ;
 #pragma unroll 2
     for (int s = s_lo; s < hi; ++s) {
