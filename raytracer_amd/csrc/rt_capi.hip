@@ -587,6 +587,7 @@ int32_t launch_render2d(rt_ctx *ctx, const rt2d_scene *scene, const rt2d_render_
         int nb = 0;
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, rtk::render2d_kernel, rtk::BLOCK, 0));
         per_cu = std::max(nb, 1);
+        if (getenv("RT_AMD_VERBOSE")) fprintf(stderr, "[rt_amd] render2d: %d CUs x %d resident workgroups\n", ctx->n_cu, per_cu);
     }
     const int64_t blocks = std::min<int64_t>(((int64_t)A.n_units + waves_per_block - 1) / waves_per_block, (int64_t)std::max(ctx->n_cu, 1) * per_cu);
     HIP_TRY(hipMemsetAsync(A.tile_counter, 0, sizeof(int32_t), ctx->stream));
