@@ -1,0 +1,78 @@
+"""The BASELINE configurations at their full image sizes, checked through properties that do not need a CPU
+render of the whole image: sample ranges add up (spectra to f32 summation tolerance, ray counts exactly),
+pixels sampled across the image equal the CPU checker's compute_pixel, the 3d BVH image equals the linear
+scan's.  Samples per pixel are kept low so that the file runs in seconds."""
+import numpy as np
+import pytest
+
+import raytracer_amd as rt
+from raytracer_amd.api import params2d, params3d
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture()
+def torch_stream(gpu_ctx):
+    gpu_ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    yield
+    torch.cuda.synchronize()
+    gpu_ctx.set_stream(None)
+
+
+@pytest.mark.parametrize("name,w,h,spp,ls", [
+    ("complex_world", 1920, 1080, 6, 2),    # configs[1]: stress test at 1080p
+    ("cornell_box", 3840, 2160, 2, 16),     # configs[2]: dispersion at 4K, many wavelengths
+])
+def test_full_size_sample_ranges_and_sampled_pixels(name, w, h, spp, ls, gpu_ctx, oracle, torch_stream):
+    world = rt.World2D(name, seed=1)
+    scene = rt.Scene2D(gpu_ctx, world)
+    whole = torch.zeros(h * w * 95, device="cuda")
+    parts = torch.zeros_like(whole)
+    a = spp // 2
+    gpu_ctx.reset_stats()
+    scene.accumulate(params2d(w, h, spp, ls, 10, seed=3), whole.data_ptr())
+    rays_whole = gpu_ctx.stats()["rays"]
+    gpu_ctx.reset_stats()
+    scene.accumulate(params2d(w, h, a, ls, 10, seed=3, sample_offset=0), parts.data_ptr())
+    scene.accumulate(params2d(w, h, spp - a, ls, 10, seed=3, sample_offset=a), parts.data_ptr())
+    st = gpu_ctx.stats()
+    assert st["rays"] == rays_whole                      # the same paths, whatever the batching
+    assert st["samples"] == w * h * spp * ls
+    assert torch.allclose(whole, parts, rtol=1e-4, atol=1e-6)
+    assert float(whole.sum()) > 0.0
+    # pixels spread over the image (corners, edges, interior) against the CPU checker's compute_pixel
+    rng = np.random.default_rng(7)
+    px = np.concatenate([[0, w - 1, 0, w - 1], rng.integers(0, w, 28)]).astype(np.int32)
+    py = np.concatenate([[0, 0, h - 1, h - 1], rng.integers(0, h, 28)]).astype(np.int32)
+    img = whole.view(h, w, 95)
+    p = params2d(w, h, spp, ls, 10, seed=3)
+    for x, y in zip(px, py):
+        want, _ = oracle.compute_pixel2d(world, p, int(x), int(y))
+        got = (img[int(y), int(x)] / spp).cpu().numpy()
+        assert np.allclose(got, want, rtol=1e-4, atol=1e-6), (x, y)
+    # and the resolve of the whole image against the resolve of those spectra
+    rgb, weight = scene.resolve(whole.data_ptr(), w, h, spp)
+    assert weight.min() == spp and weight.max() == spp
+    for x, y in zip(px[:8], py[:8]):
+        want = oracle.resolve_pixel((img[int(y), int(x)] / spp).cpu().numpy())
+        assert np.allclose(rgb[int(y), int(x)], want, rtol=1e-4, atol=1e-5)
+    scene.close()
+
+
+def test_full_size_3d_bvh_equals_linear_scan(gpu_ctx, torch_stream):
+    """configs[3]: 1080p path tracing; the reference has no BVH, so the BVH image must be the linear scan's."""
+    w, h, spp = 1920, 1080, 4
+    imgs, rays = [], []
+    for use_bvh in (False, True):
+        scene = rt.Scene3D(gpu_ctx, rt.Standalone3D(w, h, use_bvh=use_bvh))
+        buf = torch.zeros(h * w * 3, device="cuda")
+        gpu_ctx.reset_stats()
+        scene.accumulate(params3d(spp, 10, seed=5), buf.data_ptr())
+        rays.append(gpu_ctx.stats()["rays"])
+        imgs.append(buf)
+        scene.close()
+    assert rays[0] == rays[1]
+    assert torch.allclose(imgs[0], imgs[1], rtol=1e-5, atol=1e-7)
+    img = imgs[1].view(h, w, 3)
+    assert not bool(img[h - 10:, :10].any()) and bool(img[: h - 10].any())  # the reference's skipped 10x10 corner

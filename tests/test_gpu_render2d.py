@@ -3,7 +3,7 @@
 render_column) and the accumulate/resolve pair used for sample-batch sharding.
 
 Paths are bit-identical on both sides (same Philox streams, same f64
-arithmetic); what differs is the f32 summation order of a pixel's samples (LDS
+arithmetic); what differs is the f32 summation order of a pixel's samples (f32
 atomics on the GPU) and the forward vs recursive order of the f32 factor
 product, so spectra are compared with rtol 1e-4 + atol 1e-6 and ray counts
 exactly."""
