@@ -596,4 +596,43 @@ RT_DEV void generate(Path &p, int px, int py, int width, uint32_t gsample, uint3
     p.c2 = l;
 }
 
+// Wavelength bin of lambda-sample l of (pixel, global sample): word l + 2 of the sample's Philox stream
+// (spectrum.rs:185-191 draws it with rand::random).
+RT_DEV int lambda_bin(uint32_t pix, uint32_t gsample, uint32_t l, uint32_t k0, uint32_t k1)
+{
+    const uint32_t call = 1u + (l + 2u) / 4u, word = (l + 2u) % 4u;
+    const U4 wl = philox4x32_10(pix, gsample, 0xFFFFFFFFu, call, k0, k1);
+    const uint32_t r = (word == 0u) ? wl.x : (word == 1u) ? wl.y : (word == 2u) ? wl.z : wl.w;
+    return (int)(((uint64_t)r * (uint64_t)NBINS) >> 32);
+}
+
+// The part of generate() that all lambda-samples of one (pixel, global sample) share - origin and direction -
+// plus the wavelength bins of its first min(n_lambda, 16) lambda-samples, one byte each in li[4].
+RT_DEV void generate_pair(double &ox, double &oy, double &dx, double &dy, uint32_t li[4], int px, int py, int width,
+                          uint32_t gsample, int n_lambda, double px_to_world, uint32_t k0, uint32_t k1)
+{
+    const uint32_t pix = (uint32_t)(width * py + px);
+    const U4 w = philox4x32_10(pix, gsample, 0xFFFFFFFFu, 0u, k0, k1);
+    const U4 w1 = philox4x32_10(pix, gsample, 0xFFFFFFFFu, 1u, k0, k1);
+    const double x = ((double)px + u01(w.x, w.y)) - 0.5;
+    const double y = ((double)py + u01(w.z, w.w)) - 0.5;
+    ox = x * px_to_world;
+    oy = y * px_to_world;
+    sincos2pi(u01(w1.x, w1.y), dy, dx);
+    auto bin = [](uint32_t r) { return (uint32_t)(((uint64_t)r * (uint64_t)NBINS) >> 32); };
+    // lambda-samples 0, 1 are words 2, 3 of call 1; lambda-sample l >= 2 is word (l + 2) % 4 of call 1 + (l + 2) / 4
+    li[0] = bin(w1.z) | (bin(w1.w) << 8);
+    li[1] = li[2] = li[3] = 0u;
+    const int n = n_lambda < 16 ? n_lambda : 16;
+    for (int call = 2; 4 * (call - 1) - 2 < n; ++call) { // wave-uniform trip count
+        const U4 wl = philox4x32_10(pix, gsample, 0xFFFFFFFFu, (uint32_t)call, k0, k1);
+        const int l0 = 4 * (call - 1) - 2; // lambda-sample of word 0 of this call: 2, 6, 10, 14
+        const uint32_t b4 = bin(wl.x) | (bin(wl.y) << 8) | (bin(wl.z) << 16) | (bin(wl.w) << 24);
+        // bytes l0 .. l0 + 3 of the 16-byte table: l0 = 2 (mod 4), so they straddle two words
+        const int wi = l0 >> 2;
+        li[wi] |= b4 << 16;
+        if (wi + 1 < 4) li[wi + 1] |= b4 >> 16;
+    }
+}
+
 } // namespace rt2d

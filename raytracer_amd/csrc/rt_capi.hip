@@ -482,6 +482,7 @@ int32_t check_params2d(const rt2d_render_params *p)
     if (p->spp <= 0 || p->lambda_samples <= 0) return fail(RT_E_INVALID, "spp and lambda_samples must be positive");
     if (p->recursion_limit < 0 || p->recursion_limit > 4095) return fail(RT_E_LIMIT, "recursion_limit must be in 0..4095");
     if ((int64_t)p->spp * p->lambda_samples > (1 << 24)) return fail(RT_E_LIMIT, "spp * lambda_samples must be <= 2^24 per call");
+    if (p->lambda_samples > (1 << 16)) return fail(RT_E_LIMIT, "lambda_samples must be <= 65536");
     if (p->sample_offset < 0 || (int64_t)p->sample_offset + p->spp > 0x7fffffffLL) return fail(RT_E_INVALID, "sample range out of bounds");
     if ((int64_t)p->width * p->height > (1LL << 30)) return fail(RT_E_LIMIT, "image larger than 2^30 pixels");
     if (!std::isfinite(p->px_to_world) || p->px_to_world <= 0.0 ||
@@ -574,10 +575,12 @@ int32_t launch_render2d(rt_ctx *ctx, const rt2d_scene *scene, const rt2d_render_
         A.ls_shift = sh;
     }
     {
-        // work units of about 1024 items: small against a wave's share of the launch, large against the refill rate
-        const int64_t total = (int64_t)rtk::TILE2D_PIXELS * p->spp * p->lambda_samples;
-        const int64_t runs = std::max<int64_t>(1, std::min<int64_t>((total + 1023) / 1024, (0x7fffffffLL - 65536) / tiles));
-        A.chunk = (int32_t)((total + runs - 1) / runs);
+        // work units of about 1024 items (a multiple of 64 pairs): small against a wave's share of the launch,
+        // large against the refill rate
+        const int64_t total = (int64_t)rtk::TILE2D_PIXELS * p->spp; // pairs of a tile
+        int64_t unit_pairs = std::max<int64_t>(64, ((1024 / p->lambda_samples + 63) / 64) * 64);
+        unit_pairs = std::max<int64_t>(unit_pairs, ((total * tiles / (0x7fffffffLL - 65536) + 64) / 64) * 64); // unit ids fit an int
+        A.chunk = (int32_t)std::min<int64_t>(unit_pairs, ((total + 63) / 64) * 64);
         A.n_units = (int32_t)(tiles * ((total + A.chunk - 1) / A.chunk));
     }
     // persistent waves: as many workgroups as can be resident at once, never more waves than units

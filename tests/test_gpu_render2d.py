@@ -24,6 +24,8 @@ TOL = dict(rtol=1e-4, atol=1e-6)
     ("cornell_box", 40, 30, 3, 5),          # lambda_samples > 2: second Philox call for wavelength draws
     ("cornell_box_absorption", 37, 29, 2, 1),  # ragged tiles (not multiples of 8)
     ("spectrum_world", 64, 8, 3, 2),
+    ("cornell_box", 24, 18, 2, 21),         # more lambda-samples than the ray pool's 16-entry wavelength table
+    ("simple_world", 9, 5, 70, 1),          # a single partial tile, many samples
 ])
 def test_global_render_matches_checker(name, w, h, spp, ls, gpu_ctx, oracle):
     world = rt.World2D(name, seed=1)
