@@ -569,33 +569,6 @@ RT_DEV void rand_hemisphere_wave(bool need, double nx, double ny, uint32_t c0, u
     }
 }
 
-// Primary ray of (pixel, global sample) and the wavelength bin of lambda-sample l
-// (librt2d_reverse.rs:88-94).  Every lambda-sample of one sample re-derives the
-// same jitter and angle from the same counters, so the reference's "one ray for
-// all lambda samples" holds without sharing state between lanes.
-RT_DEV void generate(Path &p, int px, int py, int width, uint32_t gsample, uint32_t l, double px_to_world,
-                     int recursion_limit, uint32_t k0, uint32_t k1)
-{
-    const uint32_t pix = (uint32_t)(width * py + px);
-    const U4 w = philox4x32_10(pix, gsample, 0xFFFFFFFFu, 0u, k0, k1);
-    const U4 w1 = philox4x32_10(pix, gsample, 0xFFFFFFFFu, 1u, k0, k1);
-    double x = ((double)px + u01(w.x, w.y)) - 0.5;
-    double y = ((double)py + u01(w.z, w.w)) - 0.5;
-    p.ox = x * px_to_world;
-    p.oy = y * px_to_world;
-    sincos2pi(u01(w1.x, w1.y), p.dy, p.dx);
-    const uint32_t call = 1u + (l + 2u) / 4u, word = (l + 2u) % 4u;
-    U4 wl = w1;
-    if (call != 1u) wl = philox4x32_10(pix, gsample, 0xFFFFFFFFu, call, k0, k1);
-    const uint32_t r = (word == 0u) ? wl.x : (word == 1u) ? wl.y : (word == 2u) ? wl.z : wl.w;
-    p.li = (int)(((uint64_t)r * (uint64_t)NBINS) >> 32);
-    p.thr = 1.0f;
-    p.depth_left = recursion_limit;
-    p.c0 = pix;
-    p.c1 = gsample;
-    p.c2 = l;
-}
-
 // Wavelength bin of lambda-sample l of (pixel, global sample): word l + 2 of the sample's Philox stream
 // (spectrum.rs:185-191 draws it with rand::random).
 RT_DEV int lambda_bin(uint32_t pix, uint32_t gsample, uint32_t l, uint32_t k0, uint32_t k1)
@@ -606,8 +579,11 @@ RT_DEV int lambda_bin(uint32_t pix, uint32_t gsample, uint32_t l, uint32_t k0, u
     return (int)(((uint64_t)r * (uint64_t)NBINS) >> 32);
 }
 
-// The part of generate() that all lambda-samples of one (pixel, global sample) share - origin and direction -
-// plus the wavelength bins of its first min(n_lambda, 16) lambda-samples, one byte each in li[4].
+// Primary ray of (pixel, global sample) (librt2d_reverse.rs:88-94) - the reference draws ONE ray per sample and
+// traces it once per lambda-sample (:90-101) - plus the wavelength bins of its first min(n_lambda, 16)
+// lambda-samples, one byte each in li[4].  Philox counter (pixel, sample, 0xFFFFFFFF, call): call 0 = pixel
+// jitter, call 1 = direction angle (words 0, 1) and the first two wavelength draws, calls 2.. = four wavelength
+// draws each.
 RT_DEV void generate_pair(double &ox, double &oy, double &dx, double &dy, uint32_t li[4], int px, int py, int width,
                           uint32_t gsample, int n_lambda, double px_to_world, uint32_t k0, uint32_t k1)
 {
