@@ -505,15 +505,21 @@ RT_DEV ShadeResult shade(SceneK S, Path &p, const Hit &h, float &value, double &
 __constant__ const uint32_t HELPERS[65] = { 0x0, 0x40040, 0x80020, 0xC3115, 0x100010, 0x15560C, 0x199A0A, 0x1C7209, 0x200008, 0x249307, 0x2AAB06, 0x333405, 0x333405, 0x400004, 0x400004, 0x400004, 0x400004, 0x555603, 0x555603, 0x555603, 0x555603, 0x555603, 0x800002, 0x800002, 0x800002, 0x800002, 0x800002, 0x800002, 0x800002, 0x800002, 0x800002, 0x800002, 0x800002, 0x1000001, 0x1000001, 0x1000001, 0x1000001, 0x1000001, 0x1000001, 0x1000001, 0x1000001, 0x1000001, 0x1000001, 0x1000001, 0x1000001, 0x1000001, 0x1000001, 0x1000001, 0x1000001, 0x1000001, 0x1000001, 0x1000001, 0x1000001, 0x1000001, 0x1000001, 0x1000001, 0x1000001, 0x1000001, 0x1000001, 0x1000001, 0x1000001, 0x1000001, 0x1000001, 0x1000001, 0x1000001 };
 
 RT_DEV void rand_hemisphere_wave(bool need, double nx, double ny, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t bounce,
-                                 uint32_t k0, uint32_t k1, double &rx, double &ry)
+                                 uint32_t k0, uint32_t k1, double &rx, double &ry, Prof &prof)
 {
     uint64_t pending = __ballot(need);
     if (pending == 0) return;
+#ifdef RT_PROF
+    prof.t[15] += (unsigned long long)__popcll(pending);
+#endif
     const int lane = lane_id();
     bool still = need;
     uint32_t base = 0;
     double ovx = 0.0, ovy = 0.0, ol2 = 1.0;
     while (pending != 0) {
+#ifdef RT_PROF
+        prof.t[14] += 1;
+#endif
         const int nd = __popcll(pending);
         const int H = HELPERS[nd] & 0xFF; // 64 / nd >= 1, wave-uniform
         int tl = lane, toff = 0;

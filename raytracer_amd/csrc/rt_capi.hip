@@ -616,8 +616,8 @@ int32_t launch_render2d(rt_ctx *ctx, const rt2d_scene *scene, const rt2d_render_
         HIP_TRY(hipStreamSynchronize(ctx->stream));
         HIP_TRY(hipMemcpy(h, A.prof_out, sizeof h, hipMemcpyDeviceToHost));
         const double tot = (double)(h[0] + h[1] + h[2] + h[3] + h[4] + h[7] + h[8] + h[9] + h[12] + h[13]);
-        fprintf(stderr, "[rt_prof] candidates per wave-step %.1f, phase-2 rounds per wave-step %.2f\n", (double)h[10] / (double)h[5],
-                (double)h[11] / (double)h[5]);
+        fprintf(stderr, "[rt_prof] candidates per wave-step %.1f, phase-2 rounds per wave-step %.2f, hemisphere rounds per wave-step %.2f for %.1f lanes\n",
+                (double)h[10] / (double)h[5], (double)h[11] / (double)h[5], (double)h[14] / (double)h[5], (double)h[15] / (double)h[5]);
         fprintf(stderr, "[rt_prof] regen %.3f phase1 %.3f phase2 %.3f classify %.3f normal %.3f bend %.3f shade-rest %.3f hemisphere %.3f tail %.3f loop %.3f | wave_steps %llu lanes/step %.2f cycles/step %.0f\n",
                 h[0] / tot, h[1] / tot, h[2] / tot, h[7] / tot, h[8] / tot, h[9] / tot, h[12] / tot, h[13] / tot, h[3] / tot, h[4] / tot, h[5],
                 (double)h[6] / (double)h[5], tot / (double)h[5]);
