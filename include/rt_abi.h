@@ -184,6 +184,21 @@ int32_t rt2d_resolve(rt_ctx *ctx, const void *d_spectrum, int32_t width, int32_t
 int32_t rt2d_compute_pixels(rt_ctx *ctx, const rt2d_scene *scene, const rt2d_render_params *params,
                             int64_t n, const int32_t *px, const int32_t *py, float *out_spectrum);
 
+/* ---- 2d: adaptive re-sampling ----------------------------------------------
+ * ReverseRenderer::denoise (librt2d_reverse.rs:337-422), one pass, on RawImage
+ * planes in device memory: d_merged_rgb f32[W*H][3] and d_merged_weight f32[W*H]
+ * (updated in place), d_loop_rgb f32[W*H][3] (read), idx = W*y + x (img.rs:93-99).
+ * |merged - loop| -> 3x3 Laplace convolution (img.rs:167-185, its un-centred
+ * window and empty 3-pixel border included) -> the `top` fraction of the pixels
+ * by value, ties in the reference's sort order -> their +-mask_size
+ * neighbourhoods -> compute_pixel on that set with `params` (spp, seed and
+ * sample_offset as the caller chooses: the reference draws fresh random numbers)
+ * -> Blending::Add of (to_dvec3, spp * oversampling_factor).  out_recomputed
+ * (nullable) = size of the set, pixels outside the image included.             */
+int32_t rt2d_denoise(rt_ctx *ctx, const rt2d_scene *scene, const rt2d_render_params *params, float top,
+                     int32_t mask_size, float oversampling_factor, void *d_merged_rgb,
+                     void *d_merged_weight, const void *d_loop_rgb, int64_t *out_recomputed);
+
 /* ---- 2d: fed ray batches --------------------------------------------------
  * ReverseRenderer::trace_ray (librt2d_reverse.rs:112-262) for n rays:
  * radiance[k] = trace_ray(world, Ray2d{(ox,oy),(dx,dy)}, lambda_idx[k],

@@ -610,6 +610,110 @@ int rto2d_compute_pixel(const rto2d_scene *sc, const rto2d_params *p, int32_t px
     return 0;
 }
 
+/* ------------------------------------------------------------------------- */
+/* ReverseRenderer::denoise, 2d/src/librt2d_reverse.rs:337-422: adaptive re-sampling of the noisiest pixels.
+ * Images are RawImage planes: rgb[W*H][3] (PixelData.value) and weight[W*H], idx = W*y + x (img.rs:93-99). */
+
+/* |merged - loop| (img.rs Sub :279-300, abs :144-155), then RawImage::convolution with the 3x3 Laplace kernel
+ * (img.rs:167-185: output (x, y) = sum over i, j in 0..3, i outer, of in(x + i, y + j) * k[i][j], only for
+ * x < W - 3 and y < H - 3, the rest stays 0), then value = splat(length) (librt2d_reverse.rs:353-358) and the
+ * sort key value.length() (:368).  key[idx] is what the reference sorts by. */
+static void denoise_keys(int W, int H, const float *merged_rgb, const float *loop_rgb, float *key)
+{
+    static const float K[3][3] = { { -1.f, -1.f, -1.f }, { -1.f, 8.f, -1.f }, { -1.f, -1.f, -1.f } };
+    size_t n = (size_t)W * (size_t)H;
+    float *diff = (float *)malloc(n * 3 * sizeof(float));
+    for (size_t i = 0; i < n * 3; ++i) diff[i] = fabsf(merged_rgb[i] - loop_rgb[i]);
+    for (size_t i = 0; i < n; ++i) key[i] = 0.0f; /* length of splat(0) */
+    for (int x = 0; x < W - 3; ++x)
+        for (int y = 0; y < H - 3; ++y) {
+            float v[3] = { 0.f, 0.f, 0.f };
+            for (int i = 0; i < 3; ++i)
+                for (int j = 0; j < 3; ++j) {
+                    const float *px = diff + 3 * ((size_t)W * (size_t)(y + j) + (size_t)(x + i));
+                    for (int c = 0; c < 3; ++c) v[c] = v[c] + px[c] * K[i][j];
+                }
+            float len = sqrtf((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]); /* glam Vec3::length */
+            key[(size_t)W * (size_t)y + (size_t)x] = sqrtf((len * len + len * len) + len * len);
+        }
+    free(diff);
+}
+
+typedef struct { float key; int64_t idx; } keyed;
+
+/* sort_by(total_cmp) is stable; the reference then reverses (:368-369): descending key, and among equal
+ * keys descending index.  Keys are non-negative or NaN-free here (sqrt of sums of squares), so the float
+ * order is total_cmp's order. */
+static int keyed_cmp_desc(const void *a, const void *b)
+{
+    const keyed *x = (const keyed *)a, *y = (const keyed *)b;
+    int32_t kx, ky;
+    memcpy(&kx, &x->key, 4);
+    memcpy(&ky, &y->key, 4);
+    kx ^= (int32_t)((uint32_t)(kx >> 31) >> 1);
+    ky ^= (int32_t)((uint32_t)(ky >> 31) >> 1);
+    if (kx != ky) return kx > ky ? -1 : 1;
+    if (x->idx != y->idx) return x->idx > y->idx ? -1 : 1;
+    return 0;
+}
+
+int rto2d_denoise(const rto2d_scene *sc, const rto2d_params *p, float top, int32_t mask_size,
+                  float oversampling_factor, int32_t n_threads, float *merged_rgb, float *merged_weight,
+                  const float *loop_rgb, float *out_key, int64_t *out_recomputed, uint64_t *rays)
+{
+    if (!sc || !p || !merged_rgb || !merged_weight || !loop_rgb || mask_size < 0) return -1;
+    const int W = p->width, H = p->height;
+    const size_t n = (size_t)W * (size_t)H;
+    prep2d pp;
+    int rc = prep2d_init(&pp, sc);
+    if (rc) { prep2d_free(&pp); return rc; }
+    float *key = (float *)malloc(n * sizeof(float));
+    keyed *order = (keyed *)malloc(n * sizeof(keyed));
+    denoise_keys(W, H, merged_rgb, loop_rgb, key);
+    if (out_key) memcpy(out_key, key, n * sizeof(float));
+    for (size_t i = 0; i < n; ++i) { order[i].key = key[i]; order[i].idx = (int64_t)i; }
+    qsort(order, n, sizeof(keyed), keyed_cmp_desc);
+    /* `(total_pixels as f32 * denoiser.top) as usize` (:372-373): f32 product, saturating cast */
+    float topf = (float)(int32_t)(W * H) * top;
+    size_t n_top = topf > 0.0f ? (topf >= (float)n ? n : (size_t)topf) : 0;
+    /* the HashSet of mask pixels (:380-392), here a bitmap over the image grown by mask_size on every side:
+     * pixels outside the image are recomputed too (and dropped by draw_pixel's Err) */
+    const int m = mask_size, EW = W + 2 * m, EH = H + 2 * m;
+    uint8_t *mask = (uint8_t *)calloc((size_t)EW * (size_t)EH, 1);
+    for (size_t k = 0; k < n_top; ++k) {
+        int x = (int)(order[k].idx % W), y = (int)(order[k].idx / W);
+        for (int i = -m; i <= m; ++i)
+            for (int j = -m; j <= m; ++j) mask[(size_t)EW * (size_t)(y + j + m) + (size_t)(x + i + m)] = 1;
+    }
+    size_t cnt = 0;
+    for (size_t i = 0; i < (size_t)EW * (size_t)EH; ++i) cnt += mask[i];
+    int32_t *lx = (int32_t *)malloc((cnt + 1) * sizeof(int32_t)), *ly = (int32_t *)malloc((cnt + 1) * sizeof(int32_t));
+    size_t c = 0;
+    for (int ey = 0; ey < EH; ++ey)
+        for (int ex = 0; ex < EW; ++ex)
+            if (mask[(size_t)EW * (size_t)ey + (size_t)ex]) { lx[c] = ex - m; ly[c] = ey - m; ++c; }
+    /* recompute (:402-409) and add (:410-418): value += spectrum.to_dvec3(), weight += spp * oversampling_factor */
+    uint64_t total_rays = 0;
+    const float wadd = (float)p->spp * oversampling_factor;
+#pragma omp parallel for schedule(dynamic, 16) num_threads(n_threads > 0 ? n_threads : 1) reduction(+ : total_rays)
+    for (int64_t k = 0; k < (int64_t)cnt; ++k) {
+        float spec[RTO_NBINS], rgb[3];
+        uint64_t r = 0;
+        compute_pixel2d(&pp, p, lx[k], ly[k], spec, &r);
+        total_rays += r;
+        if (lx[k] < 0 || ly[k] < 0 || lx[k] >= W || ly[k] >= H) continue; /* pixel_to_idx -> Err */
+        rto_resolve_pixel(spec, rgb);
+        size_t idx = (size_t)W * (size_t)ly[k] + (size_t)lx[k];
+        for (int ch = 0; ch < 3; ++ch) merged_rgb[3 * idx + ch] = merged_rgb[3 * idx + ch] + rgb[ch];
+        merged_weight[idx] = merged_weight[idx] + wadd;
+    }
+    if (out_recomputed) *out_recomputed = (int64_t)cnt;
+    if (rays) *rays = total_rays;
+    free(lx); free(ly); free(mask); free(order); free(key);
+    prep2d_free(&pp);
+    return 0;
+}
+
 /* Spectrum::to_xyz + to_dvec3, 2d/src/spectrum.rs:242-278; palette Xyz<D65> -> Srgb:
  * linear = M * XYZ (sRGB/D65 matrix), then the sRGB transfer function, no clamping. */
 void rto_resolve_pixel(const float spectrum[RTO_NBINS], float rgb[3])

@@ -118,6 +118,12 @@ int rto2d_trace_batch(const rto2d_scene *sc, int64_t n, const double *ox, const 
                       int32_t *bounces);
 int rto2d_compute_pixel(const rto2d_scene *sc, const rto2d_params *p, int32_t px, int32_t py,
                         float *spectrum95, uint64_t *rays);
+/* ReverseRenderer::denoise (2d/src/librt2d_reverse.rs:337-422) on RawImage planes rgb[W*H][3], weight[W*H]:
+ * merged is updated in place; out_key (nullable) [W*H] = the value the reference sorts pixels by;
+ * out_recomputed = size of the pixel set (pixels outside the image included, as in the reference). */
+int rto2d_denoise(const rto2d_scene *sc, const rto2d_params *p, float top, int32_t mask_size,
+                  float oversampling_factor, int32_t n_threads, float *merged_rgb, float *merged_weight,
+                  const float *loop_rgb, float *out_key, int64_t *out_recomputed, uint64_t *rays);
 /* whole image, reference decomposition: serial over columns, threads over rows */
 int rto2d_render(const rto2d_scene *sc, const rto2d_params *p, int32_t n_threads, float *out_rgb,
                  float *out_weight, float *out_spectrum, uint64_t *rays);

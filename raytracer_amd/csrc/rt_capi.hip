@@ -4,6 +4,7 @@
 #include "../../include/rt_abi.h"
 
 #include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
 
 #include <algorithm>
 #include <cmath>
@@ -726,6 +727,84 @@ int32_t rt2d_compute_pixels(rt_ctx *ctx, const rt2d_scene *scene, const rt2d_ren
     if (int32_t rc = launch_render2d(ctx, scene, p, 1, n, d_px, d_py, d_out, lo_px, hi_px)) return rc;
     HIP_TRY(hipMemcpyAsync(out_spectrum, d_out, sizeof(float) * (size_t)n * RT_NBINS, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return RT_OK;
+}
+
+int32_t rt2d_denoise(rt_ctx *ctx, const rt2d_scene *scene, const rt2d_render_params *p, float top, int32_t mask_size,
+                     float oversampling_factor, void *d_merged_rgb, void *d_merged_weight, const void *d_loop_rgb,
+                     int64_t *out_recomputed)
+{
+    if (int32_t rc = ctx_bind(ctx)) return rc;
+    if (!scene || scene->ctx != ctx) return fail(RT_E_INVALID, "scene does not belong to this context");
+    if (int32_t rc = check_params2d(p)) return rc;
+    if (!d_merged_rgb || !d_merged_weight || !d_loop_rgb) return fail(RT_E_INVALID, "null image plane");
+    if (!(top >= 0.0f) || !std::isfinite(top) || !std::isfinite(oversampling_factor)) return fail(RT_E_INVALID, "top must be >= 0 and finite");
+    if (mask_size < 0 || mask_size > 1024) return fail(RT_E_LIMIT, "mask_size must be in 0..1024");
+    const int W = p->width, H = p->height, m = mask_size;
+    const int64_t n = (int64_t)W * H;
+    if (out_recomputed) *out_recomputed = 0;
+    // `(total_pixels as f32 * denoiser.top) as usize` (librt2d_reverse.rs:372-373)
+    const float topf = (float)(int32_t)n * top;
+    const int64_t n_top = topf > 0.0f ? (topf >= (float)n ? n : (int64_t)topf) : 0;
+    if (n_top == 0) return RT_OK;
+    const int EW = W + 2 * m, EH = H + 2 * m;
+    const int64_t n_cells = (int64_t)EW * EH;
+
+    struct DevBuf { // freed on every exit path, after the stream has drained
+        hipStream_t st; std::vector<void *> ptrs;
+        ~DevBuf() { (void)hipStreamSynchronize(st); for (void *q : ptrs) (void)hipFree(q); }
+        int32_t get(size_t bytes, void **out) {
+            hipError_t e = hipMalloc(out, bytes ? bytes : 1);
+            if (e != hipSuccess) return fail(RT_E_OOM, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e));
+            ptrs.push_back(*out);
+            return RT_OK;
+        }
+    } buf{ ctx->stream, {} };
+    uint64_t *keys = nullptr, *sorted = nullptr;
+    uint8_t *mask = nullptr;
+    unsigned long long *counter = nullptr;
+    void *tmp = nullptr;
+    if (int32_t rc = buf.get(sizeof(uint64_t) * (size_t)n, (void **)&keys)) return rc;
+    if (int32_t rc = buf.get(sizeof(uint64_t) * (size_t)n, (void **)&sorted)) return rc;
+    if (int32_t rc = buf.get((size_t)n_cells, (void **)&mask)) return rc;
+    if (int32_t rc = buf.get(sizeof(unsigned long long), (void **)&counter)) return rc;
+    size_t tmp_bytes = 0;
+    HIP_TRY(hipcub::DeviceRadixSort::SortKeysDescending(nullptr, tmp_bytes, keys, sorted, (int)n, 0, 64, ctx->stream));
+    if (int32_t rc = buf.get(tmp_bytes, &tmp)) return rc;
+
+    const unsigned nb = (unsigned)((n + rtk::BLOCK - 1) / rtk::BLOCK);
+    hipLaunchKernelGGL(rtk::denoise_keys_kernel, dim3(nb), dim3(rtk::BLOCK), 0, ctx->stream, (const float *)d_merged_rgb,
+                       (const float *)d_loop_rgb, W, H, keys);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipcub::DeviceRadixSort::SortKeysDescending(tmp, tmp_bytes, keys, sorted, (int)n, 0, 64, ctx->stream));
+    HIP_TRY(hipMemsetAsync(mask, 0, (size_t)n_cells, ctx->stream));
+    HIP_TRY(hipMemsetAsync(counter, 0, sizeof(unsigned long long), ctx->stream));
+    hipLaunchKernelGGL(rtk::denoise_mark_kernel, dim3((unsigned)((n_top + rtk::BLOCK - 1) / rtk::BLOCK)), dim3(rtk::BLOCK), 0,
+                       ctx->stream, sorted, n_top, W, m, mask);
+    HIP_TRY(hipGetLastError());
+    const unsigned ncb = (unsigned)((n_cells + rtk::BLOCK - 1) / rtk::BLOCK);
+    hipLaunchKernelGGL(rtk::denoise_list_kernel, dim3(ncb), dim3(rtk::BLOCK), 0, ctx->stream, mask, EW, n_cells, m,
+                       (int32_t *)nullptr, (int32_t *)nullptr, counter); // count only
+    HIP_TRY(hipGetLastError());
+    unsigned long long cnt = 0;
+    HIP_TRY(hipMemcpyAsync(&cnt, counter, sizeof cnt, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (out_recomputed) *out_recomputed = (int64_t)cnt;
+    if (cnt == 0) return RT_OK;
+    if (cnt > (1ull << 30)) return fail(RT_E_LIMIT, "more than 2^30 pixels to recompute");
+    int32_t *lx = nullptr, *ly = nullptr;
+    float *spec = nullptr;
+    if (int32_t rc = buf.get(sizeof(int32_t) * cnt, (void **)&lx)) return rc;
+    if (int32_t rc = buf.get(sizeof(int32_t) * cnt, (void **)&ly)) return rc;
+    if (int32_t rc = buf.get(sizeof(float) * cnt * RT_NBINS, (void **)&spec)) return rc;
+    HIP_TRY(hipMemsetAsync(counter, 0, sizeof(unsigned long long), ctx->stream));
+    hipLaunchKernelGGL(rtk::denoise_list_kernel, dim3(ncb), dim3(rtk::BLOCK), 0, ctx->stream, mask, EW, n_cells, m, lx, ly, counter);
+    HIP_TRY(hipGetLastError());
+    const double lo_px[2] = { (double)-m, (double)-m }, hi_px[2] = { (double)(W - 1 + m), (double)(H - 1 + m) };
+    if (int32_t rc = launch_render2d(ctx, scene, p, 1, (int64_t)cnt, lx, ly, spec, lo_px, hi_px)) return rc;
+    hipLaunchKernelGGL(rtk::denoise_add_kernel, dim3((unsigned)((cnt + 63) / 64)), dim3(64), 0, ctx->stream, spec, lx, ly, (int64_t)cnt,
+                       W, H, (float)p->spp * oversampling_factor, (float *)d_merged_rgb, (float *)d_merged_weight);
+    HIP_TRY(hipGetLastError());
     return RT_OK;
 }
 

@@ -40,6 +40,8 @@ class Oracle:
                                         fp, ip, dp, ip]
         L.rto2d_compute_pixel.argtypes = [C.POINTER(Scene2DDesc), C.POINTER(OParams2D), C.c_int32, C.c_int32, fp,
                                           C.POINTER(C.c_uint64)]
+        L.rto2d_denoise.argtypes = [C.POINTER(Scene2DDesc), C.POINTER(OParams2D), C.c_float, C.c_int32, C.c_float, C.c_int32, fp, fp, fp,
+                                    fp, C.POINTER(C.c_int64), C.POINTER(C.c_uint64)]
         L.rto2d_render.argtypes = [C.POINTER(Scene2DDesc), C.POINTER(OParams2D), C.c_int32, fp, fp, fp,
                                    C.POINTER(C.c_uint64)]
         L.rto3d_trace_batch.argtypes = [C.POINTER(Scene3DDesc), C.c_int64, dp, dp, C.c_int32, C.c_uint64, fp, ip, dp, ip]
@@ -131,6 +133,20 @@ class Oracle:
         rc = self.L.rto2d_compute_pixel(C.byref(world.desc), C.byref(op), int(x), int(y), _p(out, C.c_float), C.byref(rays))
         assert rc == 0, rc
         return out, rays.value
+
+    def denoise2d(self, world, p, top, mask_size, oversampling, merged_rgb, merged_weight, loop_rgb, threads=8):
+        """Returns (merged_rgb, merged_weight, key, recomputed, rays); inputs are not modified."""
+        rgb = np.ascontiguousarray(merged_rgb, np.float32).copy()
+        w = np.ascontiguousarray(merged_weight, np.float32).copy()
+        lp = np.ascontiguousarray(loop_rgb, np.float32)
+        key = np.zeros(p.width * p.height, np.float32)
+        n, rays = C.c_int64(), C.c_uint64()
+        op = self.params2d(p)
+        rc = self.L.rto2d_denoise(C.byref(world.desc), C.byref(op), float(top), int(mask_size), float(oversampling), int(threads),
+                                  _p(rgb, C.c_float), _p(w, C.c_float), _p(lp, C.c_float), _p(key, C.c_float), C.byref(n),
+                                  C.byref(rays))
+        assert rc == 0, rc
+        return rgb, w, key.reshape(p.height, p.width), n.value, rays.value
 
     def render2d(self, world, p, threads=8, want_spectrum=True):
         n = p.width * p.height
