@@ -1,6 +1,8 @@
 // Front-end with the parameters of the reference's batch renderer (2d/src/bin/2d_reverse.rs:15-58):
 // 800x600, spp 500, recursion limit 10, 2 lambda samples, frames of sample_world(t), Reinhard{1.} PNGs.
-// Usage: rt2d_reverse [frames=1] [spp=500] [world=sample_world] [width=800] [out_prefix=out_]
+// Usage: rt2d_reverse [frames=1] [spp=500] [world=sample_world] [width=800] [out_prefix=out_] [loops=0] [denoise=0]
+// loops > 0 renders every frame with endless_render under StopCondition::MaxLoops(loops) (librt2d_reverse.rs:424-510)
+// instead of one global_render; denoise = 1 adds the Denoiser the reference binary constructs (2d_reverse.rs:21-26).
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -18,6 +20,8 @@ int main(int argc, char **argv)
     const std::string world_name = argc > 3 ? argv[3] : "sample_world";
     const int width = argc > 4 ? atoi(argv[4]) : 800;
     const std::string prefix = argc > 5 ? argv[5] : "out_";
+    const size_t loops = argc > 6 ? (size_t)atoi(argv[6]) : 0;
+    const bool with_denoiser = argc > 7 && atoi(argv[7]) != 0;
     const int height = width * 3 / 4;
 
     ReverseRenderParams params;
@@ -27,6 +31,14 @@ int main(int argc, char **argv)
     params.recursion_limit = 10;
     params.lambda_samples = 2;
     params.px_to_world = 800.0 / width;
+    params.stop_condition.max_loops = loops;
+    if (with_denoiser) {
+        params.has_denoiser = true;
+        params.denoiser.top = 0.01f;
+        params.denoiser.oversampling_factor = 10.0f;
+        params.denoiser.mask_size = 2;
+        params.denoiser.passes = 1;
+    }
     const Camera camera{ DVec2(800.0, 600.0) / 2.0, DVec2(800.0, 600.0) / 2.0 };
     try {
         ReverseRenderer renderer(params);
@@ -35,7 +47,8 @@ int main(int argc, char **argv)
             printf("%d/%d\n", idx, frames - 1);
             const double t = (double)idx / (double)(frames > 1 ? frames : 60);
             const World world = worlds::by_name(world_name, camera, t, (uint64_t)idx, 1);
-            const RawImage raw = renderer.global_render(world, params);
+            const RawImage raw = loops > 0 ? renderer.endless_render(world, [](size_t n, const RawImage &) { printf("loop %zu\n", n); return true; })
+                                           : renderer.global_render(world, params);
             std::vector<float> rgb((size_t)width * height * 3);
             for (size_t i = 0; i < raw.data.size(); ++i) {
                 rgb[3 * i] = raw.data[i].value.x; rgb[3 * i + 1] = raw.data[i].value.y; rgb[3 * i + 2] = raw.data[i].value.z;

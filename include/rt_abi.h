@@ -186,18 +186,24 @@ int32_t rt2d_compute_pixels(rt_ctx *ctx, const rt2d_scene *scene, const rt2d_ren
 
 /* ---- 2d: adaptive re-sampling ----------------------------------------------
  * ReverseRenderer::denoise (librt2d_reverse.rs:337-422), one pass, on RawImage
- * planes in device memory: d_merged_rgb f32[W*H][3] and d_merged_weight f32[W*H]
- * (updated in place), d_loop_rgb f32[W*H][3] (read), idx = W*y + x (img.rs:93-99).
+ * planes: merged_rgb f32[W*H][3] and merged_weight f32[W*H] (updated in place),
+ * loop_rgb f32[W*H][3] (read), idx = W*y + x (img.rs:93-99).
  * |merged - loop| -> 3x3 Laplace convolution (img.rs:167-185, its un-centred
  * window and empty 3-pixel border included) -> the `top` fraction of the pixels
  * by value, ties in the reference's sort order -> their +-mask_size
  * neighbourhoods -> compute_pixel on that set with `params` (spp, seed and
  * sample_offset as the caller chooses: the reference draws fresh random numbers)
  * -> Blending::Add of (to_dvec3, spp * oversampling_factor).  out_recomputed
- * (nullable) = size of the set, pixels outside the image included.             */
+ * (nullable) = size of the set, pixels outside the image included.
+ * rt2d_denoise takes host planes (as rt2d_render returns them); rt2d_denoise_device
+ * takes planes in this GPU's memory and leaves its work on the context's stream. */
 int32_t rt2d_denoise(rt_ctx *ctx, const rt2d_scene *scene, const rt2d_render_params *params, float top,
-                     int32_t mask_size, float oversampling_factor, void *d_merged_rgb,
-                     void *d_merged_weight, const void *d_loop_rgb, int64_t *out_recomputed);
+                     int32_t mask_size, float oversampling_factor, float *merged_rgb,
+                     float *merged_weight, const float *loop_rgb, int64_t *out_recomputed);
+int32_t rt2d_denoise_device(rt_ctx *ctx, const rt2d_scene *scene, const rt2d_render_params *params,
+                            float top, int32_t mask_size, float oversampling_factor,
+                            void *d_merged_rgb, void *d_merged_weight, const void *d_loop_rgb,
+                            int64_t *out_recomputed);
 
 /* ---- 2d: fed ray batches --------------------------------------------------
  * ReverseRenderer::trace_ray (librt2d_reverse.rs:112-262) for n rays:

@@ -73,8 +73,10 @@ ABI = {
     "rt2d_accumulate": (C.c_int32, [C.c_void_p, C.c_void_p, C.POINTER(RenderParams2D), C.c_void_p]),
     "rt2d_resolve": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, c_float_p, c_float_p]),
     "rt2d_compute_pixels": (C.c_int32, [C.c_void_p, C.c_void_p, C.POINTER(RenderParams2D), C.c_int64, c_int32_p, c_int32_p, c_float_p]),
-    "rt2d_denoise": (C.c_int32, [C.c_void_p, C.c_void_p, C.POINTER(RenderParams2D), C.c_float, C.c_int32, C.c_float, C.c_void_p,
-                                 C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]),
+    "rt2d_denoise": (C.c_int32, [C.c_void_p, C.c_void_p, C.POINTER(RenderParams2D), C.c_float, C.c_int32, C.c_float, c_float_p,
+                                 c_float_p, c_float_p, C.POINTER(C.c_int64)]),
+    "rt2d_denoise_device": (C.c_int32, [C.c_void_p, C.c_void_p, C.POINTER(RenderParams2D), C.c_float, C.c_int32, C.c_float, C.c_void_p,
+                                        C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]),
     "rt2d_trace_batch": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int64, c_double_p, c_double_p, c_double_p, c_double_p,
                                      c_int32_p, C.c_int32, C.c_uint64, c_float_p, c_int32_p, c_double_p, c_int32_p]),
     "rt3d_scene_create": (C.c_int32, [C.c_void_p, C.POINTER(Scene3DDesc), C.POINTER(C.c_void_p)]),

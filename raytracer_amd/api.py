@@ -216,13 +216,24 @@ class Scene2D:
                                              _ffi.ptr(py, C.c_int32), _ffi.ptr(out, C.c_float)))
         return out
 
-    def denoise(self, p, top, mask_size, oversampling_factor, d_merged_rgb_ptr, d_merged_weight_ptr, d_loop_rgb_ptr):
+    def denoise_device(self, p, top, mask_size, oversampling_factor, d_merged_rgb_ptr, d_merged_weight_ptr, d_loop_rgb_ptr):
         """One pass of ReverseRenderer::denoise on device RawImage planes; returns the number of recomputed pixels."""
         n = C.c_int64(0)
-        check(_ffi.lib().rt2d_denoise(self.ctx._ctx, self._sc, C.byref(p), float(top), int(mask_size), float(oversampling_factor),
-                                      C.c_void_p(d_merged_rgb_ptr), C.c_void_p(d_merged_weight_ptr), C.c_void_p(d_loop_rgb_ptr),
-                                      C.byref(n)))
+        check(_ffi.lib().rt2d_denoise_device(self.ctx._ctx, self._sc, C.byref(p), float(top), int(mask_size),
+                                             float(oversampling_factor), C.c_void_p(d_merged_rgb_ptr),
+                                             C.c_void_p(d_merged_weight_ptr), C.c_void_p(d_loop_rgb_ptr), C.byref(n)))
         return n.value
+
+    def denoise(self, p, top, mask_size, oversampling_factor, merged_rgb, merged_weight, loop_rgb):
+        """The same on host planes (numpy): returns (merged_rgb, merged_weight, recomputed); inputs are not modified."""
+        rgb = np.ascontiguousarray(merged_rgb, np.float32).copy()
+        w = np.ascontiguousarray(merged_weight, np.float32).copy()
+        lp = np.ascontiguousarray(loop_rgb, np.float32)
+        assert rgb.size == 3 * p.width * p.height and w.size == p.width * p.height and lp.size == rgb.size
+        n = C.c_int64(0)
+        check(_ffi.lib().rt2d_denoise(self.ctx._ctx, self._sc, C.byref(p), float(top), int(mask_size), float(oversampling_factor),
+                                      _ffi.ptr(rgb, C.c_float), _ffi.ptr(w, C.c_float), _ffi.ptr(lp, C.c_float), C.byref(n)))
+        return rgb, w, n.value
 
     def render_column(self, p, i):
         return self.compute_pixels(p, np.full(p.height, i, np.int32), np.arange(p.height, dtype=np.int32))

@@ -546,7 +546,7 @@ int32_t launch_render2d(rt_ctx *ctx, const rt2d_scene *scene, const rt2d_render_
     A.recursion_limit = p->recursion_limit; A.sample_offset = p->sample_offset;
     A.k0 = (uint32_t)p->seed; A.k1 = (uint32_t)(p->seed >> 32);
     A.px_to_world = p->px_to_world;
-    A.list_mode = list_mode;
+    A.list_mode = list_mode ? 1 : 0;
     A.tiles_x = (p->width + rtk::TILE2D_W - 1) / rtk::TILE2D_W;
     A.list_px = d_px; A.list_py = d_py; A.n_list = n_list;
     A.out = d_out;
@@ -603,7 +603,7 @@ int32_t launch_render2d(rt_ctx *ctx, const rt2d_scene *scene, const rt2d_render_
     hipLaunchKernelGGL(rtk::render2d_kernel, dim3((unsigned)blocks), dim3(rtk::BLOCK), 0, ctx->stream, A);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(ev.second, ctx->stream));
-    if (list_mode) {
+    if (list_mode == 1) { // compute_pixel's `spectrum / spp`; mode 2 leaves the sums to the caller
         const int64_t nf = n_list * RT_NBINS;
         hipLaunchKernelGGL(rtk::divide_kernel, dim3((unsigned)((nf + rtk::BLOCK - 1) / rtk::BLOCK)), dim3(rtk::BLOCK), 0, ctx->stream,
                            d_out, nf, (float)p->spp);
@@ -730,9 +730,9 @@ int32_t rt2d_compute_pixels(rt_ctx *ctx, const rt2d_scene *scene, const rt2d_ren
     return RT_OK;
 }
 
-int32_t rt2d_denoise(rt_ctx *ctx, const rt2d_scene *scene, const rt2d_render_params *p, float top, int32_t mask_size,
-                     float oversampling_factor, void *d_merged_rgb, void *d_merged_weight, const void *d_loop_rgb,
-                     int64_t *out_recomputed)
+int32_t rt2d_denoise_device(rt_ctx *ctx, const rt2d_scene *scene, const rt2d_render_params *p, float top, int32_t mask_size,
+                            float oversampling_factor, void *d_merged_rgb, void *d_merged_weight, const void *d_loop_rgb,
+                            int64_t *out_recomputed)
 {
     if (int32_t rc = ctx_bind(ctx)) return rc;
     if (!scene || scene->ctx != ctx) return fail(RT_E_INVALID, "scene does not belong to this context");
@@ -750,27 +750,35 @@ int32_t rt2d_denoise(rt_ctx *ctx, const rt2d_scene *scene, const rt2d_render_par
     const int EW = W + 2 * m, EH = H + 2 * m;
     const int64_t n_cells = (int64_t)EW * EH;
 
-    struct DevBuf { // freed on every exit path, after the stream has drained
-        hipStream_t st; std::vector<void *> ptrs;
-        ~DevBuf() { (void)hipStreamSynchronize(st); for (void *q : ptrs) (void)hipFree(q); }
-        int32_t get(size_t bytes, void **out) {
-            hipError_t e = hipMalloc(out, bytes ? bytes : 1);
-            if (e != hipSuccess) return fail(RT_E_OOM, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e));
-            ptrs.push_back(*out);
-            return RT_OK;
-        }
-    } buf{ ctx->stream, {} };
-    uint64_t *keys = nullptr, *sorted = nullptr;
-    uint8_t *mask = nullptr;
-    unsigned long long *counter = nullptr;
-    void *tmp = nullptr;
-    if (int32_t rc = buf.get(sizeof(uint64_t) * (size_t)n, (void **)&keys)) return rc;
-    if (int32_t rc = buf.get(sizeof(uint64_t) * (size_t)n, (void **)&sorted)) return rc;
-    if (int32_t rc = buf.get((size_t)n_cells, (void **)&mask)) return rc;
-    if (int32_t rc = buf.get(sizeof(unsigned long long), (void **)&counter)) return rc;
+    // everything the pass needs comes from the context's workspace in one request (no allocation once it has grown):
+    // the pixel list and its spectra are sized for the most the mask can hold
+    const int64_t side = 2 * (int64_t)m + 1;
+    const int64_t max_list = std::min<int64_t>(n_cells, n_top * side * side);
+    if (max_list > (1LL << 30)) return fail(RT_E_LIMIT, "more than 2^30 pixels to recompute");
     size_t tmp_bytes = 0;
-    HIP_TRY(hipcub::DeviceRadixSort::SortKeysDescending(nullptr, tmp_bytes, keys, sorted, (int)n, 0, 64, ctx->stream));
-    if (int32_t rc = buf.get(tmp_bytes, &tmp)) return rc;
+    HIP_TRY(hipcub::DeviceRadixSort::SortKeysDescending(nullptr, tmp_bytes, (uint64_t *)nullptr, (uint64_t *)nullptr, (int)n, 0, 64,
+                                                        ctx->stream));
+    struct Plan { uint64_t *keys, *sorted; uint8_t *mask; unsigned long long *counter; char *tmp; int32_t *lx, *ly; float *spec; size_t bytes; };
+    auto plan = [&](char *base) {
+        Carver c{ base };
+        Plan q{};
+        q.keys = c.take<uint64_t>((size_t)n); q.sorted = c.take<uint64_t>((size_t)n);
+        q.mask = c.take<uint8_t>((size_t)n_cells); q.counter = c.take<unsigned long long>(1);
+        q.tmp = c.take<char>(tmp_bytes);
+        q.lx = c.take<int32_t>((size_t)max_list); q.ly = c.take<int32_t>((size_t)max_list);
+        q.spec = c.take<float>((size_t)max_list * RT_NBINS);
+        q.bytes = c.off + 256;
+        return q;
+    };
+    void *ws = nullptr;
+    if (int32_t rc = ctx_workspace(ctx, plan(nullptr).bytes, &ws)) return rc;
+    const Plan q = plan((char *)ws);
+    uint64_t *keys = q.keys, *sorted = q.sorted;
+    uint8_t *mask = q.mask;
+    unsigned long long *counter = q.counter;
+    char *tmp = q.tmp;
+    int32_t *lx = q.lx, *ly = q.ly;
+    float *spec = q.spec;
 
     const unsigned nb = (unsigned)((n + rtk::BLOCK - 1) / rtk::BLOCK);
     hipLaunchKernelGGL(rtk::denoise_keys_kernel, dim3(nb), dim3(rtk::BLOCK), 0, ctx->stream, (const float *)d_merged_rgb,
@@ -783,29 +791,45 @@ int32_t rt2d_denoise(rt_ctx *ctx, const rt2d_scene *scene, const rt2d_render_par
                        ctx->stream, sorted, n_top, W, m, mask);
     HIP_TRY(hipGetLastError());
     const unsigned ncb = (unsigned)((n_cells + rtk::BLOCK - 1) / rtk::BLOCK);
-    hipLaunchKernelGGL(rtk::denoise_list_kernel, dim3(ncb), dim3(rtk::BLOCK), 0, ctx->stream, mask, EW, n_cells, m,
-                       (int32_t *)nullptr, (int32_t *)nullptr, counter); // count only
+    hipLaunchKernelGGL(rtk::denoise_list_kernel, dim3(ncb), dim3(rtk::BLOCK), 0, ctx->stream, mask, EW, n_cells, m, lx, ly, counter);
     HIP_TRY(hipGetLastError());
-    unsigned long long cnt = 0;
+    unsigned long long cnt = 0; // the launch geometry of the re-sampling pass depends on it
     HIP_TRY(hipMemcpyAsync(&cnt, counter, sizeof cnt, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     if (out_recomputed) *out_recomputed = (int64_t)cnt;
     if (cnt == 0) return RT_OK;
-    if (cnt > (1ull << 30)) return fail(RT_E_LIMIT, "more than 2^30 pixels to recompute");
-    int32_t *lx = nullptr, *ly = nullptr;
-    float *spec = nullptr;
-    if (int32_t rc = buf.get(sizeof(int32_t) * cnt, (void **)&lx)) return rc;
-    if (int32_t rc = buf.get(sizeof(int32_t) * cnt, (void **)&ly)) return rc;
-    if (int32_t rc = buf.get(sizeof(float) * cnt * RT_NBINS, (void **)&spec)) return rc;
-    HIP_TRY(hipMemsetAsync(counter, 0, sizeof(unsigned long long), ctx->stream));
-    hipLaunchKernelGGL(rtk::denoise_list_kernel, dim3(ncb), dim3(rtk::BLOCK), 0, ctx->stream, mask, EW, n_cells, m, lx, ly, counter);
-    HIP_TRY(hipGetLastError());
+    if ((int64_t)cnt > max_list) return fail(RT_E_HIP, "pixel list overran its bound");
     const double lo_px[2] = { (double)-m, (double)-m }, hi_px[2] = { (double)(W - 1 + m), (double)(H - 1 + m) };
-    if (int32_t rc = launch_render2d(ctx, scene, p, 1, (int64_t)cnt, lx, ly, spec, lo_px, hi_px)) return rc;
+    // list mode 2: accumulated sums; denoise_add_kernel divides by spp as it reads them
+    if (int32_t rc = launch_render2d(ctx, scene, p, 2, (int64_t)cnt, lx, ly, spec, lo_px, hi_px)) return rc;
     hipLaunchKernelGGL(rtk::denoise_add_kernel, dim3((unsigned)((cnt + 63) / 64)), dim3(64), 0, ctx->stream, spec, lx, ly, (int64_t)cnt,
-                       W, H, (float)p->spp * oversampling_factor, (float *)d_merged_rgb, (float *)d_merged_weight);
+                       W, H, (float)p->spp, (float)p->spp * oversampling_factor, (float *)d_merged_rgb, (float *)d_merged_weight);
     HIP_TRY(hipGetLastError());
     return RT_OK;
+}
+
+int32_t rt2d_denoise(rt_ctx *ctx, const rt2d_scene *scene, const rt2d_render_params *p, float top, int32_t mask_size,
+                     float oversampling_factor, float *merged_rgb, float *merged_weight, const float *loop_rgb,
+                     int64_t *out_recomputed)
+{
+    if (int32_t rc = ctx_bind(ctx)) return rc;
+    if (int32_t rc = check_params2d(p)) return rc;
+    if (!merged_rgb || !merged_weight || !loop_rgb) return fail(RT_E_INVALID, "null image plane");
+    const size_t n = (size_t)p->width * (size_t)p->height;
+    float *d = nullptr; // merged rgb | loop rgb | merged weight
+    hipError_t e = hipMalloc((void **)&d, sizeof(float) * n * 7);
+    if (e != hipSuccess) return fail(RT_E_OOM, "hipMalloc(%zu): %s", sizeof(float) * n * 7, hipGetErrorString(e));
+    int32_t rc = RT_OK;
+    auto step = [&](hipError_t err, const char *what) { if (rc == RT_OK && err != hipSuccess) rc = fail(RT_E_HIP, "%s: %s", what, hipGetErrorString(err)); };
+    step(hipMemcpyAsync(d, merged_rgb, sizeof(float) * n * 3, hipMemcpyHostToDevice, ctx->stream), "upload");
+    step(hipMemcpyAsync(d + 3 * n, loop_rgb, sizeof(float) * n * 3, hipMemcpyHostToDevice, ctx->stream), "upload");
+    step(hipMemcpyAsync(d + 6 * n, merged_weight, sizeof(float) * n, hipMemcpyHostToDevice, ctx->stream), "upload");
+    if (rc == RT_OK) rc = rt2d_denoise_device(ctx, scene, p, top, mask_size, oversampling_factor, d, d + 6 * n, d + 3 * n, out_recomputed);
+    step(hipMemcpyAsync(merged_rgb, d, sizeof(float) * n * 3, hipMemcpyDeviceToHost, ctx->stream), "download");
+    step(hipMemcpyAsync(merged_weight, d + 6 * n, sizeof(float) * n, hipMemcpyDeviceToHost, ctx->stream), "download");
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d);
+    return rc;
 }
 
 int32_t rt2d_trace_batch(rt_ctx *ctx, const rt2d_scene *scene, int64_t n, const double *ox, const double *oy, const double *dx,

@@ -297,11 +297,25 @@ struct RawImage {
 };
 
 // ---- librt2d_reverse.rs -----------------------------------------------------
+// librt2d_reverse.rs:55-60
+struct Denoiser {
+    float top = 0.0f;
+    int32_t mask_size = 0;
+    float oversampling_factor = 1.0f;
+    size_t passes = 0;
+};
+
+// librt2d_reverse.rs:29-33 (StopCondition); max_loops == 0 stands for Endless
+struct StopCondition { size_t max_loops = 0; };
+
 struct ReverseRenderParams {
     int32_t width = 800, height = 600;
     size_t spp = 1;
     size_t recursion_limit = 10;
     size_t lambda_samples = 1;
+    bool has_denoiser = false; // `denoiser: Option<Denoiser>` (librt2d_reverse.rs:35-53)
+    Denoiser denoiser;
+    StopCondition stop_condition;
     // not in the reference: its generator is unseeded and its image is 800x600
     uint64_t seed = 0;
     int32_t sample_offset = 0;
@@ -380,6 +394,63 @@ public:
         check(rt2d_trace_batch(ctx_, scene_, 1, &ray.origin.x, &ray.origin.y, &ray.dir.x, &ray.dir.y, &li, (int32_t)depth,
                                render_params.seed, &out, nullptr, nullptr, nullptr));
         return out;
+    }
+
+    // librt2d_reverse.rs:337-422, one pass: re-samples the noisiest pixels of `merged` (judged against `loop`) with the
+    // samples [p.sample_offset, p.sample_offset + p.spp) and adds them.  Returns the number of recomputed pixels.
+    int64_t denoise(const World &world, const ReverseRenderParams &p, RawImage &merged, const RawImage &loop)
+    {
+        bind(world);
+        const rt2d_render_params rp = abi_params(p);
+        const size_t n = (size_t)p.width * (size_t)p.height;
+        std::vector<float> rgb(n * 3), weight(n), lrgb(n * 3);
+        for (size_t i = 0; i < n; ++i) {
+            rgb[3 * i] = merged.data[i].value.x; rgb[3 * i + 1] = merged.data[i].value.y; rgb[3 * i + 2] = merged.data[i].value.z;
+            weight[i] = merged.data[i].weight;
+            lrgb[3 * i] = loop.data[i].value.x; lrgb[3 * i + 1] = loop.data[i].value.y; lrgb[3 * i + 2] = loop.data[i].value.z;
+        }
+        int64_t recomputed = 0;
+        check(rt2d_denoise(ctx_, scene_, &rp, p.denoiser.top, p.denoiser.mask_size, p.denoiser.oversampling_factor, rgb.data(),
+                           weight.data(), lrgb.data(), &recomputed));
+        for (size_t i = 0; i < n; ++i) {
+            merged.data[i].value = Vec3{ rgb[3 * i], rgb[3 * i + 1], rgb[3 * i + 2] };
+            merged.data[i].weight = weight[i];
+        }
+        return recomputed;
+    }
+
+    // librt2d_reverse.rs:424-510 without the GUI channels: `on_progress(loops, merged)` stands for tx.try_send and
+    // returns false where the reference would have received a RenderCommand.  As in the reference a loop renders
+    // one more pass, merges it with `merged + loop` (img.rs:257-274: values add, weights are dropped) and runs the
+    // denoiser passes.  Every pass draws its own sample range, in the order the reference draws random numbers.
+    template <class Progress>
+    RawImage endless_render(const World &world, Progress on_progress)
+    {
+        ReverseRenderParams p = render_params;
+        auto next_samples = [&]() { const int32_t at = p.sample_offset; p.sample_offset += (int32_t)p.spp; return at; };
+        ReverseRenderParams q = p;
+        q.sample_offset = next_samples();
+        RawImage merged = global_render(world, q);
+        (void)on_progress((size_t)0, merged); // the reference polls for a command only inside the loop
+        for (size_t loop_n = 1;; ) {
+            if (!on_progress(loop_n, merged)) break;
+            q.sample_offset = next_samples();
+            const RawImage loop_image = global_render(world, q);
+            RawImage sum(p.width, p.height);
+            for (size_t i = 0; i < sum.data.size(); ++i) {
+                sum.data[i].value = Vec3{ merged.data[i].value.x + loop_image.data[i].value.x, merged.data[i].value.y + loop_image.data[i].value.y,
+                                          merged.data[i].value.z + loop_image.data[i].value.z };
+            }
+            merged = sum;
+            if (p.has_denoiser)
+                for (size_t pass = 0; pass < p.denoiser.passes; ++pass) {
+                    q.sample_offset = next_samples();
+                    denoise(world, q, merged, loop_image);
+                }
+            ++loop_n;
+            if (p.stop_condition.max_loops != 0 && loop_n > p.stop_condition.max_loops) break;
+        }
+        return merged;
     }
 
     std::vector<Spectrum> compute_pixels(const ReverseRenderParams &p, const std::vector<int32_t> &px, const std::vector<int32_t> &py)

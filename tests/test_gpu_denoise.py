@@ -38,7 +38,7 @@ def test_denoise_pass_matches_checker(name, w, h, top, mask, over, gpu_ctx, orac
         d_w = torch.from_numpy(merged_w).cuda().contiguous()
         d_loop = torch.from_numpy(loop_rgb).cuda().contiguous()
         gpu_ctx.reset_stats()
-        n = scene.denoise(p, top, mask, over, d_rgb.data_ptr(), d_w.data_ptr(), d_loop.data_ptr())
+        n = scene.denoise_device(p, top, mask, over, d_rgb.data_ptr(), d_w.data_ptr(), d_loop.data_ptr())
         torch.cuda.synchronize()
         rays = gpu_ctx.stats()["rays"]
         got_rgb, got_w = d_rgb.cpu().numpy(), d_w.cpu().numpy()
@@ -49,6 +49,9 @@ def test_denoise_pass_matches_checker(name, w, h, top, mask, over, gpu_ctx, orac
     assert np.array_equal(got_w, want_w)                  # exactly the same pixels were re-sampled
     assert (got_w > 0).sum() >= int(np.float32(w * h) * np.float32(top))
     assert np.allclose(got_rgb, want_rgb, rtol=2e-4, atol=2e-5)
+    # the host-plane entry does the same
+    h_rgb, h_w, h_n = scene.denoise(p, top, mask, over, merged_rgb, merged_w, loop_rgb)
+    assert h_n == n and np.array_equal(h_w, want_w) and np.allclose(h_rgb, want_rgb, rtol=2e-4, atol=2e-5)
     scene.close()
 
 
@@ -60,15 +63,15 @@ def test_denoise_arguments(gpu_ctx):
     wt = torch.zeros(16 * 16, device="cuda")
     gpu_ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     try:
-        assert scene.denoise(p, 0.0, 2, 1.0, buf.data_ptr(), wt.data_ptr(), buf.data_ptr()) == 0   # top = 0: nothing to do
+        assert scene.denoise_device(p, 0.0, 2, 1.0, buf.data_ptr(), wt.data_ptr(), buf.data_ptr()) == 0   # top = 0: nothing to do
         with pytest.raises(rt.RtError):
-            scene.denoise(p, -0.1, 2, 1.0, buf.data_ptr(), wt.data_ptr(), buf.data_ptr())
+            scene.denoise_device(p, -0.1, 2, 1.0, buf.data_ptr(), wt.data_ptr(), buf.data_ptr())
         with pytest.raises(rt.RtError):
-            scene.denoise(p, 0.1, -1, 1.0, buf.data_ptr(), wt.data_ptr(), buf.data_ptr())
+            scene.denoise_device(p, 0.1, -1, 1.0, buf.data_ptr(), wt.data_ptr(), buf.data_ptr())
         with pytest.raises(rt.RtError):
-            scene.denoise(p, 0.1, 1, 1.0, 0, wt.data_ptr(), buf.data_ptr())
+            scene.denoise_device(p, 0.1, 1, 1.0, 0, wt.data_ptr(), buf.data_ptr())
         # top >= 1 selects every pixel
-        n = scene.denoise(p, 2.0, 0, 1.0, buf.data_ptr(), wt.data_ptr(), buf.data_ptr())
+        n = scene.denoise_device(p, 2.0, 0, 1.0, buf.data_ptr(), wt.data_ptr(), buf.data_ptr())
         torch.cuda.synchronize()
         assert n == 256 and bool((wt == 1.0).all())
     finally:
