@@ -205,6 +205,64 @@ int32_t rt2d_denoise_device(rt_ctx *ctx, const rt2d_scene *scene, const rt2d_ren
                             void *d_merged_rgb, void *d_merged_weight, const void *d_loop_rgb,
                             int64_t *out_recomputed);
 
+/* ---- 2d: progressive rendering ---------------------------------------------
+ * The loop of ReverseRenderer::endless_render (librt2d_reverse.rs:424-510) with
+ * its state resident on the GPU.  Where the reference merges passes as
+ * `merged_image + loop_image` on encoded colours and drops the weights
+ * (img.rs:257-274), this object keeps per pixel the spectral SUM of every sample
+ * taken (f32[W*H][95]) and the COUNT of those samples (f32[W*H]); the image is
+ * sRGB(sum / count).  A step is one iteration of the reference's loop:
+ *   pass:      global_render with the next `spp` samples of every pixel
+ *              (:436 the first time, :463 after) -> loop image = sRGB(pass/spp);
+ *              sum += pass, count += spp; merged image = sRGB(sum / count);
+ *   resample:  from the second step on, `denoiser.passes` times
+ *              ReverseRenderer::denoise (:337-422) on (merged, loop): the same
+ *              selection as rt2d_denoise; the selected pixels then take
+ *              floor(spp * oversampling_factor) (at least 1) new samples each,
+ *              which join sum and count - the reference books exactly that
+ *              weight (:417) while tracing only spp samples.
+ * Every pass draws the next unused global sample indices, starting at
+ * params->sample_offset.  The scene must outlive the object; calls are ordered
+ * on the context's stream.                                                      */
+typedef struct rt2d_progressive rt2d_progressive;
+
+typedef struct rt2d_denoiser { /* Denoiser, librt2d_reverse.rs:55-60 */
+    float top;
+    int32_t mask_size;
+    float oversampling_factor;
+    int32_t passes;
+} rt2d_denoiser;
+
+typedef struct rt2d_progress { /* RenderProgress (rt_common.rs:563-566) without the image */
+    int64_t loops;       /* whole-image passes merged so far */
+    int64_t next_sample; /* first unused global sample index */
+    int64_t recomputed;  /* pixels re-sampled by the last step (all its passes, out-of-image ones included) */
+    uint64_t rays;       /* rays traced by the last step */
+} rt2d_progress;
+
+/* denoiser may be NULL (`denoiser: None`). */
+int32_t rt2d_progressive_create(rt_ctx *ctx, const rt2d_scene *scene, const rt2d_render_params *params,
+                                const rt2d_denoiser *denoiser, rt2d_progressive **out);
+int32_t rt2d_progressive_destroy(rt2d_progressive *prog);
+/* One iteration of the loop; out (nullable) describes the state after it. */
+int32_t rt2d_progressive_step(rt2d_progressive *prog, rt2d_progress *out);
+/* The two halves of a step, for callers that schedule them themselves:
+ * _pass is the whole-image pass and merge; _resample is ONE adaptive pass with
+ * the object's denoiser settings (RT_E_INVALID without a denoiser or before the
+ * first pass); out_recomputed nullable. */
+int32_t rt2d_progressive_pass(rt2d_progressive *prog);
+int32_t rt2d_progressive_resample(rt2d_progressive *prog, int64_t *out_recomputed);
+/* RenderProgress hand-off (librt2d_reverse.rs:450-456, gui.rs:449-475): the merged image after
+ * convert_to_image(Reinhard{param}) as host RGBA8 [W*H][4], alpha 255 (img.rs:187-218).        */
+int32_t rt2d_progressive_image(rt2d_progressive *prog, float reinhard_param, uint8_t *out_rgba8);
+/* Host copies of the state; every pointer nullable: sum f32[W*H][95], count f32[W*H],
+ * merged_rgb and loop_rgb f32[W*H][3].                                                         */
+int32_t rt2d_progressive_read(rt2d_progressive *prog, float *out_sum, float *out_count, float *out_merged_rgb,
+                              float *out_loop_rgb);
+/* The same four planes as device pointers (valid until destroy; nullable outputs). */
+int32_t rt2d_progressive_planes(rt2d_progressive *prog, void **d_sum, void **d_count, void **d_merged_rgb,
+                                void **d_loop_rgb);
+
 /* ---- 2d: fed ray batches --------------------------------------------------
  * ReverseRenderer::trace_ray (librt2d_reverse.rs:112-262) for n rays:
  * radiance[k] = trace_ray(world, Ray2d{(ox,oy),(dx,dy)}, lambda_idx[k],

@@ -554,9 +554,10 @@ int rto2d_trace_batch(const rto2d_scene *sc, int64_t n, const double *ox, const 
     return 0;
 }
 
-/* ReverseRenderer::compute_pixel, 2d/src/librt2d_reverse.rs:80-110 */
-static void compute_pixel2d(const prep2d *pp, const rto2d_params *p, int px, int py, float *total,
-                            uint64_t *rays)
+/* ReverseRenderer::compute_pixel, 2d/src/librt2d_reverse.rs:80-110, up to the final division: total[] is the
+ * sum over the samples (:107) */
+static void compute_pixel2d_sum(const prep2d *pp, const rto2d_params *p, int px, int py, float *total,
+                                uint64_t *rays)
 {
     uint32_t key[2] = { (uint32_t)p->seed, (uint32_t)(p->seed >> 32) };
     uint32_t pix = (uint32_t)(p->width * py + px);
@@ -594,6 +595,12 @@ static void compute_pixel2d(const prep2d *pp, const rto2d_params *p, int px, int
             total[k] += v;                                                     /* :107 */
         }
     }
+}
+
+static void compute_pixel2d(const prep2d *pp, const rto2d_params *p, int px, int py, float *total,
+                            uint64_t *rays)
+{
+    compute_pixel2d_sum(pp, p, px, py, total, rays);
     for (int k = 0; k < RTO_NBINS; ++k) total[k] = total[k] / (float)p->spp; /* :109 */
 }
 
@@ -657,16 +664,13 @@ static int keyed_cmp_desc(const void *a, const void *b)
     return 0;
 }
 
-int rto2d_denoise(const rto2d_scene *sc, const rto2d_params *p, float top, int32_t mask_size,
-                  float oversampling_factor, int32_t n_threads, float *merged_rgb, float *merged_weight,
-                  const float *loop_rgb, float *out_key, int64_t *out_recomputed, uint64_t *rays)
+/* The selection of denoise (:346-392): keys, stable sort + reverse, top fraction, +-mask_size neighbourhoods.
+ * Returns the recompute set as a malloc'ed list in row-major order of the image grown by mask_size on every
+ * side (the reference's HashSet has no order; results do not depend on it). */
+static size_t select_noisy(int W, int H, float top, int32_t mask_size, const float *merged_rgb, const float *loop_rgb,
+                           float *out_key, int32_t **out_lx, int32_t **out_ly)
 {
-    if (!sc || !p || !merged_rgb || !merged_weight || !loop_rgb || mask_size < 0) return -1;
-    const int W = p->width, H = p->height;
     const size_t n = (size_t)W * (size_t)H;
-    prep2d pp;
-    int rc = prep2d_init(&pp, sc);
-    if (rc) { prep2d_free(&pp); return rc; }
     float *key = (float *)malloc(n * sizeof(float));
     keyed *order = (keyed *)malloc(n * sizeof(keyed));
     denoise_keys(W, H, merged_rgb, loop_rgb, key);
@@ -692,6 +696,22 @@ int rto2d_denoise(const rto2d_scene *sc, const rto2d_params *p, float top, int32
     for (int ey = 0; ey < EH; ++ey)
         for (int ex = 0; ex < EW; ++ex)
             if (mask[(size_t)EW * (size_t)ey + (size_t)ex]) { lx[c] = ex - m; ly[c] = ey - m; ++c; }
+    free(mask); free(order); free(key);
+    *out_lx = lx; *out_ly = ly;
+    return cnt;
+}
+
+int rto2d_denoise(const rto2d_scene *sc, const rto2d_params *p, float top, int32_t mask_size,
+                  float oversampling_factor, int32_t n_threads, float *merged_rgb, float *merged_weight,
+                  const float *loop_rgb, float *out_key, int64_t *out_recomputed, uint64_t *rays)
+{
+    if (!sc || !p || !merged_rgb || !merged_weight || !loop_rgb || mask_size < 0) return -1;
+    const int W = p->width, H = p->height;
+    prep2d pp;
+    int rc = prep2d_init(&pp, sc);
+    if (rc) { prep2d_free(&pp); return rc; }
+    int32_t *lx, *ly;
+    size_t cnt = select_noisy(W, H, top, mask_size, merged_rgb, loop_rgb, out_key, &lx, &ly);
     /* recompute (:402-409) and add (:410-418): value += spectrum.to_dvec3(), weight += spp * oversampling_factor */
     uint64_t total_rays = 0;
     const float wadd = (float)p->spp * oversampling_factor;
@@ -709,7 +729,81 @@ int rto2d_denoise(const rto2d_scene *sc, const rto2d_params *p, float top, int32
     }
     if (out_recomputed) *out_recomputed = (int64_t)cnt;
     if (rays) *rays = total_rays;
-    free(lx); free(ly); free(mask); free(order); free(key);
+    free(lx); free(ly);
+    prep2d_free(&pp);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------- */
+/* Progressive accumulation in linear light: the loop of endless_render (librt2d_reverse.rs:424-510) with the
+ * pass merge done on spectral sums and per-pixel sample counts - sum f32[W*H][95], count f32[W*H] - where the
+ * reference adds encoded colours (`merged_image + loop_image`, img.rs:257-274).  Not reference arithmetic: this
+ * states the merge the GPU library's progressive entry points are specified to perform.                       */
+static void resolve_div(const float *sum95, float div, float rgb[3])
+{
+    float v[RTO_NBINS];
+    for (int k = 0; k < RTO_NBINS; ++k) v[k] = sum95[k] / div;
+    rto_resolve_pixel(v, rgb);
+}
+
+/* One whole-image pass (global_render, :282-302) of p->spp samples from p->sample_offset: loop_rgb = sRGB(pass / spp),
+ * sum += pass, count += spp, merged_rgb = sRGB(sum / count). */
+int rto2d_progressive_pass(const rto2d_scene *sc, const rto2d_params *p, int32_t n_threads, float *sum,
+                           float *count, float *merged_rgb, float *loop_rgb, uint64_t *rays)
+{
+    if (!sc || !p || !sum || !count || !merged_rgb || !loop_rgb) return -1;
+    prep2d pp;
+    int rc = prep2d_init(&pp, sc);
+    if (rc) { prep2d_free(&pp); return rc; }
+    uint64_t total_rays = 0;
+    const int64_t n = (int64_t)p->width * p->height;
+#pragma omp parallel for schedule(dynamic, 16) num_threads(n_threads > 0 ? n_threads : 1) reduction(+ : total_rays)
+    for (int64_t idx = 0; idx < n; ++idx) {
+        float pass[RTO_NBINS];
+        uint64_t r = 0;
+        compute_pixel2d_sum(&pp, p, (int)(idx % p->width), (int)(idx / p->width), pass, &r);
+        total_rays += r;
+        float *s = sum + (size_t)idx * RTO_NBINS;
+        for (int k = 0; k < RTO_NBINS; ++k) s[k] = s[k] + pass[k];
+        count[idx] = count[idx] + (float)p->spp;
+        resolve_div(pass, (float)p->spp, loop_rgb + 3 * (size_t)idx);
+        resolve_div(s, count[idx], merged_rgb + 3 * (size_t)idx);
+    }
+    if (rays) *rays = total_rays;
+    prep2d_free(&pp);
+    return 0;
+}
+
+/* One adaptive pass: the selection of denoise on (merged_rgb, loop_rgb); every selected pixel takes p->spp new
+ * samples from p->sample_offset; inside the image they join sum and count and merged_rgb is refreshed. */
+int rto2d_progressive_resample(const rto2d_scene *sc, const rto2d_params *p, float top, int32_t mask_size,
+                               int32_t n_threads, float *sum, float *count, float *merged_rgb,
+                               const float *loop_rgb, int64_t *out_recomputed, uint64_t *rays)
+{
+    if (!sc || !p || !sum || !count || !merged_rgb || !loop_rgb || mask_size < 0) return -1;
+    const int W = p->width, H = p->height;
+    prep2d pp;
+    int rc = prep2d_init(&pp, sc);
+    if (rc) { prep2d_free(&pp); return rc; }
+    int32_t *lx, *ly;
+    size_t cnt = select_noisy(W, H, top, mask_size, merged_rgb, loop_rgb, NULL, &lx, &ly);
+    uint64_t total_rays = 0;
+#pragma omp parallel for schedule(dynamic, 16) num_threads(n_threads > 0 ? n_threads : 1) reduction(+ : total_rays)
+    for (int64_t k = 0; k < (int64_t)cnt; ++k) {
+        float add[RTO_NBINS];
+        uint64_t r = 0;
+        compute_pixel2d_sum(&pp, p, lx[k], ly[k], add, &r);
+        total_rays += r;
+        if (lx[k] < 0 || ly[k] < 0 || lx[k] >= W || ly[k] >= H) continue;
+        size_t idx = (size_t)W * (size_t)ly[k] + (size_t)lx[k];
+        float *s = sum + idx * RTO_NBINS;
+        for (int b = 0; b < RTO_NBINS; ++b) s[b] = s[b] + add[b];
+        count[idx] = count[idx] + (float)p->spp;
+        resolve_div(s, count[idx], merged_rgb + 3 * idx);
+    }
+    if (out_recomputed) *out_recomputed = (int64_t)cnt;
+    if (rays) *rays = total_rays;
+    free(lx); free(ly);
     prep2d_free(&pp);
     return 0;
 }

@@ -125,6 +125,13 @@ int rto2d_denoise(const rto2d_scene *sc, const rto2d_params *p, float top, int32
                   float oversampling_factor, int32_t n_threads, float *merged_rgb, float *merged_weight,
                   const float *loop_rgb, float *out_key, int64_t *out_recomputed, uint64_t *rays);
 /* whole image, reference decomposition: serial over columns, threads over rows */
+/* Progressive accumulation in linear light (spectral sums + per-pixel sample counts); states the merge the GPU
+ * library's rt2d_progressive_* entry points perform, see rt_oracle.c. */
+int rto2d_progressive_pass(const rto2d_scene *sc, const rto2d_params *p, int32_t n_threads, float *sum,
+                           float *count, float *merged_rgb, float *loop_rgb, uint64_t *rays);
+int rto2d_progressive_resample(const rto2d_scene *sc, const rto2d_params *p, float top, int32_t mask_size,
+                               int32_t n_threads, float *sum, float *count, float *merged_rgb,
+                               const float *loop_rgb, int64_t *out_recomputed, uint64_t *rays);
 int rto2d_render(const rto2d_scene *sc, const rto2d_params *p, int32_t n_threads, float *out_rgb,
                  float *out_weight, float *out_spectrum, uint64_t *rays);
 

@@ -39,6 +39,14 @@ class RenderParams2D(C.Structure):
                 ("px_to_world", C.c_double)]
 
 
+class Denoiser2D(C.Structure):
+    _fields_ = [("top", C.c_float), ("mask_size", C.c_int32), ("oversampling_factor", C.c_float), ("passes", C.c_int32)]
+
+
+class Progress2D(C.Structure):
+    _fields_ = [("loops", C.c_int64), ("next_sample", C.c_int64), ("recomputed", C.c_int64), ("rays", C.c_uint64)]
+
+
 class Scene3DDesc(C.Structure):
     _fields_ = [("n_spheres", C.c_int32), ("use_bvh", C.c_int32),
                 ("cx", c_double_p), ("cy", c_double_p), ("cz", c_double_p), ("r", c_double_p),
@@ -77,6 +85,16 @@ ABI = {
                                  c_float_p, c_float_p, C.POINTER(C.c_int64)]),
     "rt2d_denoise_device": (C.c_int32, [C.c_void_p, C.c_void_p, C.POINTER(RenderParams2D), C.c_float, C.c_int32, C.c_float, C.c_void_p,
                                         C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]),
+    "rt2d_progressive_create": (C.c_int32, [C.c_void_p, C.c_void_p, C.POINTER(RenderParams2D), C.POINTER(Denoiser2D),
+                                            C.POINTER(C.c_void_p)]),
+    "rt2d_progressive_destroy": (C.c_int32, [C.c_void_p]),
+    "rt2d_progressive_step": (C.c_int32, [C.c_void_p, C.POINTER(Progress2D)]),
+    "rt2d_progressive_pass": (C.c_int32, [C.c_void_p]),
+    "rt2d_progressive_resample": (C.c_int32, [C.c_void_p, C.POINTER(C.c_int64)]),
+    "rt2d_progressive_image": (C.c_int32, [C.c_void_p, C.c_float, C.POINTER(C.c_uint8)]),
+    "rt2d_progressive_read": (C.c_int32, [C.c_void_p, c_float_p, c_float_p, c_float_p, c_float_p]),
+    "rt2d_progressive_planes": (C.c_int32, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                            C.POINTER(C.c_void_p)]),
     "rt2d_trace_batch": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int64, c_double_p, c_double_p, c_double_p, c_double_p,
                                      c_int32_p, C.c_int32, C.c_uint64, c_float_p, c_int32_p, c_double_p, c_int32_p]),
     "rt3d_scene_create": (C.c_int32, [C.c_void_p, C.POINTER(Scene3DDesc), C.POINTER(C.c_void_p)]),

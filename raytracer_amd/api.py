@@ -177,6 +177,70 @@ def params2d(width, height, spp, lambda_samples, recursion_limit, seed=0, sample
     return p
 
 
+class Progressive2D:
+    """The loop of ReverseRenderer::endless_render (2d/src/librt2d_reverse.rs:424-510) with its state on the GPU:
+    spectral sums and per-pixel sample counts.  `denoiser` = (top, mask_size, oversampling_factor, passes) or None."""
+
+    def __init__(self, scene, p, denoiser=None):
+        self.scene, self.width, self.height = scene, p.width, p.height
+        self._g = C.c_void_p()
+        dn = None
+        if denoiser is not None:
+            dn = _ffi.Denoiser2D(float(denoiser[0]), int(denoiser[1]), float(denoiser[2]), int(denoiser[3]))
+        check(_ffi.lib().rt2d_progressive_create(scene.ctx._ctx, scene._sc, C.byref(p), C.byref(dn) if dn is not None else None,
+                                                 C.byref(self._g)))
+        if not hasattr(scene, "_progressives"):
+            scene._progressives = weakref.WeakSet()
+        scene._progressives.add(self)
+
+    def step(self):
+        """One loop iteration; returns dict(loops, next_sample, recomputed, rays)."""
+        out = _ffi.Progress2D()
+        check(_ffi.lib().rt2d_progressive_step(self._g, C.byref(out)))
+        return {"loops": out.loops, "next_sample": out.next_sample, "recomputed": out.recomputed, "rays": out.rays}
+
+    def render_pass(self):
+        check(_ffi.lib().rt2d_progressive_pass(self._g))
+
+    def resample(self):
+        n = C.c_int64(0)
+        check(_ffi.lib().rt2d_progressive_resample(self._g, C.byref(n)))
+        return n.value
+
+    def image(self, reinhard_param=1.0):
+        out = np.empty((self.height, self.width, 4), np.uint8)
+        check(_ffi.lib().rt2d_progressive_image(self._g, float(reinhard_param), out.ctypes.data_as(C.POINTER(C.c_uint8))))
+        return out
+
+    def read(self, sum=True, count=True, merged=True, loop=True):
+        """Host copies (sum [H,W,95], count [H,W], merged_rgb [H,W,3], loop_rgb [H,W,3]); None where not asked."""
+        H, W = self.height, self.width
+        a = np.empty((H, W, NBINS), np.float32) if sum else None
+        b = np.empty((H, W), np.float32) if count else None
+        c = np.empty((H, W, 3), np.float32) if merged else None
+        d = np.empty((H, W, 3), np.float32) if loop else None
+        check(_ffi.lib().rt2d_progressive_read(self._g, _ffi.ptr(a, C.c_float), _ffi.ptr(b, C.c_float), _ffi.ptr(c, C.c_float),
+                                               _ffi.ptr(d, C.c_float)))
+        return a, b, c, d
+
+    def planes(self):
+        """Device addresses (sum, count, merged_rgb, loop_rgb)."""
+        ptrs = [C.c_void_p() for _ in range(4)]
+        check(_ffi.lib().rt2d_progressive_planes(self._g, *[C.byref(q) for q in ptrs]))
+        return tuple(q.value for q in ptrs)
+
+    def close(self):
+        if getattr(self, "_g", None):
+            _ffi.lib().rt2d_progressive_destroy(self._g)
+            self._g = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Scene2D:
     """A World uploaded to one GPU; methods named after ReverseRenderer's."""
 
@@ -255,8 +319,14 @@ class Scene2D:
                                           _ffi.ptr(ft, C.c_double), _ffi.ptr(nb, C.c_int32)))
         return rad, fp, ft, nb
 
+    def progressive(self, p, denoiser=None):
+        """Device-resident endless_render loop: see Progressive2D."""
+        return Progressive2D(self, p, denoiser)
+
     def close(self):
         if getattr(self, "_sc", None):
+            for g in list(getattr(self, "_progressives", ())):
+                g.close()
             _ffi.lib().rt2d_scene_destroy(self._sc)
             self._sc = None
 

@@ -90,6 +90,18 @@ struct rt2d_scene {
     int n_circles = 0;                                   // without the slot that pads an odd count
     double seg_extent = 0.0;                             // largest |b - a| component of a segment
     mutable double padded_for = -1.0;                    // filt_M the device's c32e array currently holds
+    mutable int users = 0;                               // progressive renderers bound to this scene
+};
+
+struct rt2d_progressive {
+    rt_ctx *ctx = nullptr;
+    const rt2d_scene *scene = nullptr;
+    rt2d_render_params p{};
+    rt2d_denoiser dn{};
+    bool has_dn = false;
+    float *planes = nullptr; // one allocation: sum | pass | count | merged_rgb | loop_rgb
+    float *sum = nullptr, *pass = nullptr, *count = nullptr, *merged_rgb = nullptr, *loop_rgb = nullptr;
+    int64_t loops = 0, next_sample = 0;
 };
 
 struct rt3d_scene {
@@ -464,6 +476,7 @@ int32_t rt2d_scene_create(rt_ctx *ctx, const rt2d_scene_desc *d, rt2d_scene **ou
 int32_t rt2d_scene_destroy(rt2d_scene *scene)
 {
     if (!scene) return RT_OK;
+    if (scene->users != 0) return fail(RT_E_INVALID, "scene is still bound to %d progressive renderer(s): destroy them first", scene->users);
     scene->ctx->live_scenes -= 1;
     (void)hipSetDevice(scene->ctx->device);
     (void)hipStreamSynchronize(scene->ctx->stream);
@@ -629,6 +642,72 @@ int32_t launch_render2d(rt_ctx *ctx, const rt2d_scene *scene, const rt2d_render_
     return RT_OK;
 }
 
+// The selection half of ReverseRenderer::denoise (librt2d_reverse.rs:346-392) on device planes: noise keys, sort,
+// top fraction, dilation, pixel list.  Everything comes from the context's workspace in one request (no allocation
+// once it has grown); the list and the buffer for its spectra are sized for the most the mask can hold.
+struct NoisyPixels {
+    int32_t *lx = nullptr, *ly = nullptr; // device: listed pixel coordinates, out-of-image ones included
+    float *spec = nullptr;                // device: room for count x 95 sums
+    int64_t count = 0;
+};
+
+int32_t select_noisy_pixels(rt_ctx *ctx, int W, int H, float top, int32_t mask_size, const float *d_merged_rgb,
+                            const float *d_loop_rgb, NoisyPixels *out)
+{
+    if (!(top >= 0.0f) || !std::isfinite(top)) return fail(RT_E_INVALID, "top must be >= 0 and finite");
+    if (mask_size < 0 || mask_size > 1024) return fail(RT_E_LIMIT, "mask_size must be in 0..1024");
+    *out = NoisyPixels{};
+    const int m = mask_size;
+    const int64_t n = (int64_t)W * H;
+    // `(total_pixels as f32 * denoiser.top) as usize` (librt2d_reverse.rs:372-373)
+    const float topf = (float)(int32_t)n * top;
+    const int64_t n_top = topf > 0.0f ? (topf >= (float)n ? n : (int64_t)topf) : 0;
+    if (n_top == 0) return RT_OK;
+    const int EW = W + 2 * m, EH = H + 2 * m;
+    const int64_t n_cells = (int64_t)EW * EH;
+    const int64_t side = 2 * (int64_t)m + 1;
+    const int64_t max_list = std::min<int64_t>(n_cells, n_top * side * side);
+    if (max_list > (1LL << 30)) return fail(RT_E_LIMIT, "more than 2^30 pixels to recompute");
+    size_t tmp_bytes = 0;
+    HIP_TRY(hipcub::DeviceRadixSort::SortKeysDescending(nullptr, tmp_bytes, (uint64_t *)nullptr, (uint64_t *)nullptr, (int)n, 0, 64,
+                                                        ctx->stream));
+    struct Plan { uint64_t *keys, *sorted; uint8_t *mask; unsigned long long *counter; char *tmp; int32_t *lx, *ly; float *spec; size_t bytes; };
+    auto plan = [&](char *base) {
+        Carver c{ base };
+        Plan q{};
+        q.keys = c.take<uint64_t>((size_t)n); q.sorted = c.take<uint64_t>((size_t)n);
+        q.mask = c.take<uint8_t>((size_t)n_cells + 4); q.counter = c.take<unsigned long long>(1);
+        q.tmp = c.take<char>(tmp_bytes);
+        q.lx = c.take<int32_t>((size_t)max_list); q.ly = c.take<int32_t>((size_t)max_list);
+        q.spec = c.take<float>((size_t)max_list * RT_NBINS);
+        q.bytes = c.off + 256;
+        return q;
+    };
+    void *ws = nullptr;
+    if (int32_t rc = ctx_workspace(ctx, plan(nullptr).bytes, &ws)) return rc;
+    const Plan q = plan((char *)ws);
+
+    const unsigned nb = (unsigned)((n + rtk::BLOCK - 1) / rtk::BLOCK);
+    hipLaunchKernelGGL(rtk::denoise_keys_kernel, dim3(nb), dim3(rtk::BLOCK), 0, ctx->stream, d_merged_rgb, d_loop_rgb, W, H, q.keys);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipcub::DeviceRadixSort::SortKeysDescending(q.tmp, tmp_bytes, q.keys, q.sorted, (int)n, 0, 64, ctx->stream));
+    HIP_TRY(hipMemsetAsync(q.mask, 0, (size_t)n_cells + 4, ctx->stream)); // the list kernel reads whole 4-byte words
+    HIP_TRY(hipMemsetAsync(q.counter, 0, sizeof(unsigned long long), ctx->stream));
+    hipLaunchKernelGGL(rtk::denoise_mark_kernel, dim3((unsigned)((n_top + rtk::BLOCK - 1) / rtk::BLOCK)), dim3(rtk::BLOCK), 0,
+                       ctx->stream, q.sorted, n_top, W, m, q.mask);
+    HIP_TRY(hipGetLastError());
+    const unsigned ncb = (unsigned)((n_cells + rtk::LIST_CELLS_PER_WAVE - 1) / rtk::LIST_CELLS_PER_WAVE);
+    hipLaunchKernelGGL(rtk::denoise_list_kernel, dim3(ncb), dim3(64), 0, ctx->stream, q.mask, EW, n_cells, m, q.lx, q.ly,
+                       q.counter);
+    HIP_TRY(hipGetLastError());
+    unsigned long long cnt = 0; // the launch geometry of the re-sampling pass depends on it
+    HIP_TRY(hipMemcpyAsync(&cnt, q.counter, sizeof cnt, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if ((int64_t)cnt > max_list) return fail(RT_E_HIP, "pixel list overran its bound");
+    out->lx = q.lx; out->ly = q.ly; out->spec = q.spec; out->count = (int64_t)cnt;
+    return RT_OK;
+}
+
 } // namespace
 
 extern "C" {
@@ -738,72 +817,19 @@ int32_t rt2d_denoise_device(rt_ctx *ctx, const rt2d_scene *scene, const rt2d_ren
     if (!scene || scene->ctx != ctx) return fail(RT_E_INVALID, "scene does not belong to this context");
     if (int32_t rc = check_params2d(p)) return rc;
     if (!d_merged_rgb || !d_merged_weight || !d_loop_rgb) return fail(RT_E_INVALID, "null image plane");
-    if (!(top >= 0.0f) || !std::isfinite(top) || !std::isfinite(oversampling_factor)) return fail(RT_E_INVALID, "top must be >= 0 and finite");
-    if (mask_size < 0 || mask_size > 1024) return fail(RT_E_LIMIT, "mask_size must be in 0..1024");
-    const int W = p->width, H = p->height, m = mask_size;
-    const int64_t n = (int64_t)W * H;
+    if (!std::isfinite(oversampling_factor)) return fail(RT_E_INVALID, "oversampling_factor must be finite");
     if (out_recomputed) *out_recomputed = 0;
-    // `(total_pixels as f32 * denoiser.top) as usize` (librt2d_reverse.rs:372-373)
-    const float topf = (float)(int32_t)n * top;
-    const int64_t n_top = topf > 0.0f ? (topf >= (float)n ? n : (int64_t)topf) : 0;
-    if (n_top == 0) return RT_OK;
-    const int EW = W + 2 * m, EH = H + 2 * m;
-    const int64_t n_cells = (int64_t)EW * EH;
-
-    // everything the pass needs comes from the context's workspace in one request (no allocation once it has grown):
-    // the pixel list and its spectra are sized for the most the mask can hold
-    const int64_t side = 2 * (int64_t)m + 1;
-    const int64_t max_list = std::min<int64_t>(n_cells, n_top * side * side);
-    if (max_list > (1LL << 30)) return fail(RT_E_LIMIT, "more than 2^30 pixels to recompute");
-    size_t tmp_bytes = 0;
-    HIP_TRY(hipcub::DeviceRadixSort::SortKeysDescending(nullptr, tmp_bytes, (uint64_t *)nullptr, (uint64_t *)nullptr, (int)n, 0, 64,
-                                                        ctx->stream));
-    struct Plan { uint64_t *keys, *sorted; uint8_t *mask; unsigned long long *counter; char *tmp; int32_t *lx, *ly; float *spec; size_t bytes; };
-    auto plan = [&](char *base) {
-        Carver c{ base };
-        Plan q{};
-        q.keys = c.take<uint64_t>((size_t)n); q.sorted = c.take<uint64_t>((size_t)n);
-        q.mask = c.take<uint8_t>((size_t)n_cells); q.counter = c.take<unsigned long long>(1);
-        q.tmp = c.take<char>(tmp_bytes);
-        q.lx = c.take<int32_t>((size_t)max_list); q.ly = c.take<int32_t>((size_t)max_list);
-        q.spec = c.take<float>((size_t)max_list * RT_NBINS);
-        q.bytes = c.off + 256;
-        return q;
-    };
-    void *ws = nullptr;
-    if (int32_t rc = ctx_workspace(ctx, plan(nullptr).bytes, &ws)) return rc;
-    const Plan q = plan((char *)ws);
-    uint64_t *keys = q.keys, *sorted = q.sorted;
-    uint8_t *mask = q.mask;
-    unsigned long long *counter = q.counter;
-    char *tmp = q.tmp;
-    int32_t *lx = q.lx, *ly = q.ly;
-    float *spec = q.spec;
-
-    const unsigned nb = (unsigned)((n + rtk::BLOCK - 1) / rtk::BLOCK);
-    hipLaunchKernelGGL(rtk::denoise_keys_kernel, dim3(nb), dim3(rtk::BLOCK), 0, ctx->stream, (const float *)d_merged_rgb,
-                       (const float *)d_loop_rgb, W, H, keys);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipcub::DeviceRadixSort::SortKeysDescending(tmp, tmp_bytes, keys, sorted, (int)n, 0, 64, ctx->stream));
-    HIP_TRY(hipMemsetAsync(mask, 0, (size_t)n_cells, ctx->stream));
-    HIP_TRY(hipMemsetAsync(counter, 0, sizeof(unsigned long long), ctx->stream));
-    hipLaunchKernelGGL(rtk::denoise_mark_kernel, dim3((unsigned)((n_top + rtk::BLOCK - 1) / rtk::BLOCK)), dim3(rtk::BLOCK), 0,
-                       ctx->stream, sorted, n_top, W, m, mask);
-    HIP_TRY(hipGetLastError());
-    const unsigned ncb = (unsigned)((n_cells + rtk::BLOCK - 1) / rtk::BLOCK);
-    hipLaunchKernelGGL(rtk::denoise_list_kernel, dim3(ncb), dim3(rtk::BLOCK), 0, ctx->stream, mask, EW, n_cells, m, lx, ly, counter);
-    HIP_TRY(hipGetLastError());
-    unsigned long long cnt = 0; // the launch geometry of the re-sampling pass depends on it
-    HIP_TRY(hipMemcpyAsync(&cnt, counter, sizeof cnt, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
-    if (out_recomputed) *out_recomputed = (int64_t)cnt;
-    if (cnt == 0) return RT_OK;
-    if ((int64_t)cnt > max_list) return fail(RT_E_HIP, "pixel list overran its bound");
+    const int W = p->width, H = p->height, m = mask_size;
+    NoisyPixels px;
+    if (int32_t rc = select_noisy_pixels(ctx, W, H, top, mask_size, (const float *)d_merged_rgb, (const float *)d_loop_rgb, &px)) return rc;
+    if (out_recomputed) *out_recomputed = px.count;
+    if (px.count == 0) return RT_OK;
     const double lo_px[2] = { (double)-m, (double)-m }, hi_px[2] = { (double)(W - 1 + m), (double)(H - 1 + m) };
     // list mode 2: accumulated sums; denoise_add_kernel divides by spp as it reads them
-    if (int32_t rc = launch_render2d(ctx, scene, p, 2, (int64_t)cnt, lx, ly, spec, lo_px, hi_px)) return rc;
-    hipLaunchKernelGGL(rtk::denoise_add_kernel, dim3((unsigned)((cnt + 63) / 64)), dim3(64), 0, ctx->stream, spec, lx, ly, (int64_t)cnt,
-                       W, H, (float)p->spp, (float)p->spp * oversampling_factor, (float *)d_merged_rgb, (float *)d_merged_weight);
+    if (int32_t rc = launch_render2d(ctx, scene, p, 2, px.count, px.lx, px.ly, px.spec, lo_px, hi_px)) return rc;
+    hipLaunchKernelGGL(rtk::denoise_add_kernel, dim3((unsigned)((px.count + 63) / 64)), dim3(64), 0, ctx->stream, px.spec, px.lx, px.ly,
+                       px.count, W, H, (float)p->spp, (float)p->spp * oversampling_factor, (float *)d_merged_rgb,
+                       (float *)d_merged_weight);
     HIP_TRY(hipGetLastError());
     return RT_OK;
 }
@@ -830,6 +856,165 @@ int32_t rt2d_denoise(rt_ctx *ctx, const rt2d_scene *scene, const rt2d_render_par
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipFree(d);
     return rc;
+}
+
+int32_t rt2d_progressive_create(rt_ctx *ctx, const rt2d_scene *scene, const rt2d_render_params *p, const rt2d_denoiser *dn,
+                                rt2d_progressive **out)
+{
+    if (int32_t rc = ctx_bind(ctx)) return rc;
+    if (!out) return fail(RT_E_INVALID, "null out");
+    *out = nullptr;
+    if (!scene || scene->ctx != ctx) return fail(RT_E_INVALID, "scene does not belong to this context");
+    if (int32_t rc = check_params2d(p)) return rc;
+    if (dn) {
+        if (!(dn->top >= 0.0f) || !std::isfinite(dn->top)) return fail(RT_E_INVALID, "top must be >= 0 and finite");
+        if (dn->mask_size < 0 || dn->mask_size > 1024) return fail(RT_E_LIMIT, "mask_size must be in 0..1024");
+        if (!(dn->oversampling_factor > 0.0f) || !std::isfinite(dn->oversampling_factor) ||
+            (double)p->spp * dn->oversampling_factor > 1048576.0)
+            return fail(RT_E_INVALID, "spp * oversampling_factor must be in (0, 2^20]");
+        if (dn->passes < 0) return fail(RT_E_INVALID, "negative passes");
+    }
+    auto *g = new rt2d_progressive;
+    g->ctx = ctx; g->scene = scene; g->p = *p;
+    if (dn) { g->dn = *dn; g->has_dn = true; }
+    g->next_sample = p->sample_offset;
+    const size_t n = (size_t)p->width * (size_t)p->height;
+    Carver sizing{ nullptr }; // every plane 256-byte aligned (the merge kernel moves 16 bytes per lane)
+    sizing.take<float>(n * RT_NBINS); sizing.take<float>(n * RT_NBINS); sizing.take<float>(n); sizing.take<float>(3 * n); sizing.take<float>(3 * n);
+    const size_t bytes = sizing.off + 256;
+    hipError_t e = hipMalloc((void **)&g->planes, bytes);
+    if (e != hipSuccess) { delete g; return fail(RT_E_OOM, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e)); }
+    Carver c{ (char *)g->planes };
+    g->sum = c.take<float>(n * RT_NBINS); g->pass = c.take<float>(n * RT_NBINS); g->count = c.take<float>(n);
+    g->merged_rgb = c.take<float>(3 * n); g->loop_rgb = c.take<float>(3 * n);
+    e = hipMemsetAsync(g->planes, 0, bytes, ctx->stream);
+    if (e != hipSuccess) { (void)hipFree(g->planes); delete g; return fail(RT_E_HIP, "memset: %s", hipGetErrorString(e)); }
+    scene->users += 1;
+    *out = g;
+    return RT_OK;
+}
+
+int32_t rt2d_progressive_destroy(rt2d_progressive *g)
+{
+    if (!g) return RT_OK;
+    (void)hipSetDevice(g->ctx->device);
+    (void)hipStreamSynchronize(g->ctx->stream);
+    (void)hipFree(g->planes);
+    g->scene->users -= 1;
+    delete g;
+    return RT_OK;
+}
+
+int32_t rt2d_progressive_pass(rt2d_progressive *g)
+{
+    if (!g) return fail(RT_E_INVALID, "null progressive renderer");
+    if (int32_t rc = ctx_bind(g->ctx)) return rc;
+    rt_ctx *ctx = g->ctx;
+    if (g->next_sample + g->p.spp > 0x7fffffffLL) return fail(RT_E_LIMIT, "global sample index would pass 2^31");
+    const int64_t n = (int64_t)g->p.width * g->p.height;
+    rt2d_render_params q = g->p;
+    q.sample_offset = (int32_t)g->next_sample;
+    HIP_TRY(hipMemsetAsync(g->pass, 0, sizeof(float) * (size_t)n * RT_NBINS, ctx->stream));
+    if (int32_t rc = launch_render2d(ctx, g->scene, &q, 0, 0, nullptr, nullptr, g->pass)) return rc;
+    hipLaunchKernelGGL(rtk::progressive_merge_kernel, dim3((unsigned)((n + rtk::MERGE_PIXELS - 1) / rtk::MERGE_PIXELS)), dim3(64), 0,
+                       ctx->stream, g->pass, n, (float)g->p.spp, g->sum, g->count, g->merged_rgb, g->loop_rgb);
+    HIP_TRY(hipGetLastError());
+    g->next_sample += g->p.spp;
+    g->loops += 1;
+    return RT_OK;
+}
+
+int32_t rt2d_progressive_resample(rt2d_progressive *g, int64_t *out_recomputed)
+{
+    if (!g) return fail(RT_E_INVALID, "null progressive renderer");
+    if (int32_t rc = ctx_bind(g->ctx)) return rc;
+    if (out_recomputed) *out_recomputed = 0;
+    if (!g->has_dn) return fail(RT_E_INVALID, "no denoiser was given at create");
+    if (g->loops < 1) return fail(RT_E_INVALID, "no pass has been rendered yet");
+    rt_ctx *ctx = g->ctx;
+    const int W = g->p.width, H = g->p.height, m = g->dn.mask_size;
+    // the weight the reference books for a re-sampled pixel (librt2d_reverse.rs:417) is the number of samples taken here
+    const int32_t spp_r = std::max<int32_t>(1, (int32_t)((float)g->p.spp * g->dn.oversampling_factor));
+    if (g->next_sample + spp_r > 0x7fffffffLL) return fail(RT_E_LIMIT, "global sample index would pass 2^31");
+    NoisyPixels px;
+    if (int32_t rc = select_noisy_pixels(ctx, W, H, g->dn.top, m, g->merged_rgb, g->loop_rgb, &px)) return rc;
+    if (out_recomputed) *out_recomputed = px.count;
+    if (px.count == 0) return RT_OK;
+    rt2d_render_params q = g->p;
+    q.spp = spp_r;
+    q.sample_offset = (int32_t)g->next_sample;
+    if (int32_t rc = check_params2d(&q)) return rc;
+    const double lo_px[2] = { (double)-m, (double)-m }, hi_px[2] = { (double)(W - 1 + m), (double)(H - 1 + m) };
+    if (int32_t rc = launch_render2d(ctx, g->scene, &q, 2, px.count, px.lx, px.ly, px.spec, lo_px, hi_px)) return rc;
+    hipLaunchKernelGGL(rtk::progressive_add_kernel, dim3((unsigned)((px.count + 63) / 64)), dim3(64), 0, ctx->stream, px.spec, px.lx,
+                       px.ly, px.count, W, H, (float)spp_r, g->sum, g->count, g->merged_rgb);
+    HIP_TRY(hipGetLastError());
+    g->next_sample += spp_r;
+    return RT_OK;
+}
+
+int32_t rt2d_progressive_step(rt2d_progressive *g, rt2d_progress *out)
+{
+    if (!g) return fail(RT_E_INVALID, "null progressive renderer");
+    if (int32_t rc = ctx_bind(g->ctx)) return rc;
+    rt_stats before{}, after{};
+    if (int32_t rc = rt_ctx_get_stats(g->ctx, &before)) return rc;
+    const bool first = g->loops == 0; // the reference's initial global_render comes without denoiser passes (:436)
+    if (int32_t rc = rt2d_progressive_pass(g)) return rc;
+    int64_t recomputed = 0;
+    if (g->has_dn && !first)
+        for (int32_t k = 0; k < g->dn.passes; ++k) {
+            int64_t c = 0;
+            if (int32_t rc = rt2d_progressive_resample(g, &c)) return rc;
+            recomputed += c;
+        }
+    if (out) {
+        if (int32_t rc = rt_ctx_get_stats(g->ctx, &after)) return rc;
+        out->loops = g->loops; out->next_sample = g->next_sample; out->recomputed = recomputed;
+        out->rays = after.rays - before.rays;
+    }
+    return RT_OK;
+}
+
+int32_t rt2d_progressive_image(rt2d_progressive *g, float reinhard_param, uint8_t *out_rgba8)
+{
+    if (!g) return fail(RT_E_INVALID, "null progressive renderer");
+    if (int32_t rc = ctx_bind(g->ctx)) return rc;
+    if (!out_rgba8) return fail(RT_E_INVALID, "null out_rgba8");
+    rt_ctx *ctx = g->ctx;
+    const int64_t n = (int64_t)g->p.width * g->p.height;
+    void *ws = nullptr;
+    if (int32_t rc = ctx_workspace(ctx, sizeof(uint32_t) * (size_t)n, &ws)) return rc;
+    hipLaunchKernelGGL(rtk::reinhard_kernel, dim3((unsigned)((n + rtk::BLOCK - 1) / rtk::BLOCK)), dim3(rtk::BLOCK), 0, ctx->stream,
+                       g->merged_rgb, n, reinhard_param, 255u, (uint32_t *)ws);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out_rgba8, ws, sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return RT_OK;
+}
+
+int32_t rt2d_progressive_read(rt2d_progressive *g, float *out_sum, float *out_count, float *out_merged_rgb, float *out_loop_rgb)
+{
+    if (!g) return fail(RT_E_INVALID, "null progressive renderer");
+    if (int32_t rc = ctx_bind(g->ctx)) return rc;
+    const size_t n = (size_t)g->p.width * (size_t)g->p.height;
+    hipStream_t st = g->ctx->stream;
+    if (out_sum) HIP_TRY(hipMemcpyAsync(out_sum, g->sum, sizeof(float) * n * RT_NBINS, hipMemcpyDeviceToHost, st));
+    if (out_count) HIP_TRY(hipMemcpyAsync(out_count, g->count, sizeof(float) * n, hipMemcpyDeviceToHost, st));
+    if (out_merged_rgb) HIP_TRY(hipMemcpyAsync(out_merged_rgb, g->merged_rgb, sizeof(float) * n * 3, hipMemcpyDeviceToHost, st));
+    if (out_loop_rgb) HIP_TRY(hipMemcpyAsync(out_loop_rgb, g->loop_rgb, sizeof(float) * n * 3, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return RT_OK;
+}
+
+int32_t rt2d_progressive_planes(rt2d_progressive *g, void **d_sum, void **d_count, void **d_merged_rgb, void **d_loop_rgb)
+{
+    if (!g) return fail(RT_E_INVALID, "null progressive renderer");
+    if (d_sum) *d_sum = g->sum;
+    if (d_count) *d_count = g->count;
+    if (d_merged_rgb) *d_merged_rgb = g->merged_rgb;
+    if (d_loop_rgb) *d_loop_rgb = g->loop_rgb;
+    return RT_OK;
 }
 
 int32_t rt2d_trace_batch(rt_ctx *ctx, const rt2d_scene *scene, int64_t n, const double *ox, const double *oy, const double *dx,

@@ -44,6 +44,10 @@ class Oracle:
                                     fp, C.POINTER(C.c_int64), C.POINTER(C.c_uint64)]
         L.rto2d_render.argtypes = [C.POINTER(Scene2DDesc), C.POINTER(OParams2D), C.c_int32, fp, fp, fp,
                                    C.POINTER(C.c_uint64)]
+        L.rto2d_progressive_pass.argtypes = [C.POINTER(Scene2DDesc), C.POINTER(OParams2D), C.c_int32, fp, fp, fp, fp,
+                                             C.POINTER(C.c_uint64)]
+        L.rto2d_progressive_resample.argtypes = [C.POINTER(Scene2DDesc), C.POINTER(OParams2D), C.c_float, C.c_int32, C.c_int32,
+                                                 fp, fp, fp, fp, C.POINTER(C.c_int64), C.POINTER(C.c_uint64)]
         L.rto3d_trace_batch.argtypes = [C.POINTER(Scene3DDesc), C.c_int64, dp, dp, C.c_int32, C.c_uint64, fp, ip, dp, ip]
         L.rto3d_camera_rays.argtypes = [C.POINTER(Scene3DDesc), C.POINTER(RenderParams3D), C.c_int64, ip, ip, ip, dp, dp]
         L.rto3d_render.argtypes = [C.POINTER(Scene3DDesc), C.POINTER(RenderParams3D), C.c_int32, C.c_int32, fp,
@@ -147,6 +151,28 @@ class Oracle:
                                   C.byref(rays))
         assert rc == 0, rc
         return rgb, w, key.reshape(p.height, p.width), n.value, rays.value
+
+    def progressive_pass(self, world, p, sum_, count, threads=8):
+        """In place on sum_ [H,W,95] and count [H,W]; returns (merged_rgb, loop_rgb, rays)."""
+        merged = np.zeros((p.height, p.width, 3), np.float32)
+        loop = np.zeros((p.height, p.width, 3), np.float32)
+        rays = C.c_uint64()
+        op = self.params2d(p)
+        rc = self.L.rto2d_progressive_pass(C.byref(world.desc), C.byref(op), int(threads), _p(sum_, C.c_float), _p(count, C.c_float),
+                                           _p(merged, C.c_float), _p(loop, C.c_float), C.byref(rays))
+        assert rc == 0, rc
+        return merged, loop, rays.value
+
+    def progressive_resample(self, world, p, top, mask_size, sum_, count, merged_rgb, loop_rgb, threads=8):
+        """In place on sum_, count and merged_rgb; p.spp = samples per selected pixel; returns (recomputed, rays)."""
+        n, rays = C.c_int64(), C.c_uint64()
+        op = self.params2d(p)
+        lp = np.ascontiguousarray(loop_rgb, np.float32)
+        rc = self.L.rto2d_progressive_resample(C.byref(world.desc), C.byref(op), float(top), int(mask_size), int(threads),
+                                               _p(sum_, C.c_float), _p(count, C.c_float), _p(merged_rgb, C.c_float), _p(lp, C.c_float),
+                                               C.byref(n), C.byref(rays))
+        assert rc == 0, rc
+        return n.value, rays.value
 
     def render2d(self, world, p, threads=8, want_spectrum=True):
         n = p.width * p.height
