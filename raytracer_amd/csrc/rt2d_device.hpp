@@ -33,11 +33,8 @@ typedef const double __attribute__((address_space(4))) *K_f64;
 typedef const float __attribute__((address_space(4))) *K_f32;
 struct SegX;
 typedef const SegX __attribute__((address_space(4))) *K_SegX;
-// A segment as the f32 filter reads it (32 bytes, one scalar load): s = b - a, cs = A x s and A = a - frame centre.
-struct Seg32 { float sx, sy, cs, ax, ay, pad_[3]; };
-typedef const Seg32 __attribute__((address_space(4))) *K_Seg32;
-// Error bounds of the segment filter for one launch (see filter_word).
-struct SegBounds { float ed, et, eu, ew, euew, eted; };
+// Margins of the segment filter for one launch (see filter_word).
+struct SegBounds { float eq, ep; };
 
 // Scene in HBM.  Slot order: circles by ascending pid, then segments by ascending pid.
 // A circle as the exact test and the shading read it: one 32-byte record, two 16-byte loads from one address.
@@ -65,7 +62,10 @@ struct SceneDev {
     const double *ior, *inv_ior; // [n_ior][95]: Ior::ior(lambda_i) and its reciprocal (rt_common.rs:442-450)
     const CircleX *cex;
     const SegX *sex;
-    const Seg32 *seg32;
+    // segments as the f32 filter reads them: five arrays of seg_stride floats each (the count padded to even), in
+    // the order sx, sy (s = b - a), cs = A x s, ax, ay (A = a - frame centre)
+    const float *seg32;
+    int32_t seg_stride, pad2_;
     SegBounds seg_bounds; // set per launch with the frame
     const MatDev *mats;
     const float *spectra;
@@ -156,9 +156,15 @@ RT_DEV bool segment_t(double ox, double oy, double rx, double ry, double ax, dou
 //      fused step): |den| 7.1 eps S, |tn| 13.1 eps B S, |un| 10.7 eps B, |un - den| 15 eps B + 10.1 eps S.
 //      With the bounds Ed = 12 eps S, Et = 16 eps B S, Eu = 12 eps B, Ew = 20 eps (B + S) (which also
 //      absorb the rounding of the products) a product x y of values known to within Ex, Ey lies
-//      within |x| Ey + |y| Ex + Ex Ey of the true one; Q and P are compared against that.  The
+//      within |x| Ey + |y| Ex + Ex Ey of the true one.  The magnitudes are bounded per launch,
+//      |un| <= 2.83 B, |un - den| <= 2.83 B + 1.42 S, |tn| <= 4.02 B S, |den| <= 1.42 S (|A - U| <= 2 sqrt2 B,
+//      |s| <= sqrt2 S), so Q and P are compared against two constants of the launch,
+//        eq = 2.83 B Ew + (2.83 B + 1.42 S) Eu + Eu Ew,   ep = 4.02 B S Ed + 1.42 S Et + Et Ed   (+1 %),
+//      instead of per-segment margins: no absolute values, and the whole test is packed arithmetic, two
+//      segments per instruction.  The constant margins pass a sliver more (a band of about eq / den^2 of
+//      the segment's length past each end, ep / den^2 behind the origin); the exact test drops those.  The
 //      reference's own f64 rounding (and its -0.0 from an underflowing quotient) is many orders of
-//      magnitude inside these margins.  13 f32 operations per segment.
+//      magnitude inside these margins.  9 packed operations per pair plus an OR and a v_alignbit per segment.
 //  phase 2 (marked slots only, shared out over the wave's lanes, see nearest_hit):
 //    the exact test in the reference's operation order, then (total_cmp key, pid)
 //    lexicographic minimum = "first minimum in scan order" (librt2d_reverse.rs:139).
@@ -167,7 +173,7 @@ RT_DEV bool segment_t(double ox, double oy, double rx, double ry, double ax, dou
 struct FilterRay {
     f32x2 ndx, dy; // -d.x, d.y
     f32x2 kc;      // d x u
-    float ux, uy, rx, ry, nku; // segments: u, d and -(u x d)
+    f32x2 nux, uy, nku; // segments: -u.x, u.y and -(u x d)
 };
 
 RT_DEV FilterRay filter_ray(SceneK S, double ox, double oy, double dx, double dy, bool &in_range)
@@ -181,13 +187,15 @@ RT_DEV FilterRay filter_ray(SceneK S, double ox, double oy, double dx, double dy
     f.ndx = f32x2{ -dxf, -dxf };
     f.dy = f32x2{ dyf, dyf };
     f.kc = f32x2{ kc, kc };
-    f.ux = (float)ux; f.uy = (float)uy; f.rx = dxf; f.ry = dyf;
-    f.nku = -(float)(ux * dy - uy * dx);
+    const float uxf = (float)ux, uyf = (float)uy, nku = -(float)(ux * dy - uy * dx);
+    f.nux = f32x2{ -uxf, -uxf };
+    f.uy = f32x2{ uyf, uyf };
+    f.nku = f32x2{ nku, nku };
     return f;
 }
 
-RT_DEV uint32_t filter_word(int n_circ, K_f32 c32x, K_f32 c32y, K_f32 c32e, K_Seg32 seg32, const SegBounds &E, int lo, int hi, double ox, double oy, double dx,
-                            double dy, const FilterRay &f, uint32_t force)
+RT_DEV uint32_t filter_word(int n_circ, K_f32 c32x, K_f32 c32y, K_f32 c32e, K_f32 seg32, int seg_stride, const SegBounds &E, int lo, int hi,
+                            const FilterRay &f, uint32_t force)
 {
     uint32_t acc = 0;
     const int c_end = hi < n_circ ? hi : n_circ;
@@ -203,24 +211,38 @@ RT_DEV uint32_t filter_word(int n_circ, K_f32 c32x, K_f32 c32y, K_f32 c32e, K_Se
         acc = __builtin_amdgcn_alignbit(acc, __float_as_uint(g.x), 31); // collects the sign of g: set = drop
         acc = __builtin_amdgcn_alignbit(acc, __float_as_uint(g.y), 31);
     }
-    // keep iff g >= 0.  The ones this puts above the bits collected so far are shifted out below: by the end
-    // exactly hi - lo bits have been appended and the word is shifted up by 32 - (hi - lo).
-    acc = ~acc;
+    // two segments per packed instruction as well (the segment arrays are padded to an even count; the first
+    // segment slot, n_circ, is even).  Drop bits again: sign(rq) | sign(rp).
     const int s_lo = lo > n_circ ? lo : n_circ;
+    const K_f32 a_sx = seg32, a_sy = seg32 + seg_stride, a_cs = seg32 + 2 * seg_stride, a_ax = seg32 + 3 * seg_stride,
+                a_ay = seg32 + 4 * seg_stride;
+    const f32x2 eq = { E.eq, E.eq }, ep = { E.ep, E.ep };
+    auto pair = [&](int k, f32x2 &rq, f32x2 &rp) {
+        const f32x2 sx = *(K_f32x2)(a_sx + k), sy = *(K_f32x2)(a_sy + k), cs = *(K_f32x2)(a_cs + k);
+        const f32x2 ax = *(K_f32x2)(a_ax + k), ay = *(K_f32x2)(a_ay + k);
+        const f32x2 den = __builtin_elementwise_fma(-f.ndx, sy, -(f.dy * sx));                              // d x s
+        const f32x2 tn = __builtin_elementwise_fma(f.uy, sx, __builtin_elementwise_fma(f.nux, sy, cs));     // (A - U) x s
+        const f32x2 un = __builtin_elementwise_fma(ax, f.dy, __builtin_elementwise_fma(ay, f.ndx, f.nku));  // (A - U) x d
+        const f32x2 w = un - den;
+        rq = __builtin_elementwise_fma(-un, w, eq);  // < 0: u surely outside [0, 1]
+        rp = __builtin_elementwise_fma(tn, den, ep); // < 0: t surely negative
+    };
+    int s = s_lo;
 #pragma unroll 2
-    for (int s = s_lo; s < hi; ++s) {
-        const K_Seg32 gp = seg32 + (s - n_circ);
-        const struct { float sx, sy, cs, ax, ay; } g = { gp->sx, gp->sy, gp->cs, gp->ax, gp->ay };
-        const float den = __builtin_fmaf(f.rx, g.sy, -(f.ry * g.sx));
-        const float tn = __builtin_fmaf(f.uy, g.sx, __builtin_fmaf(-f.ux, g.sy, g.cs));
-        const float un = __builtin_fmaf(g.ax, f.ry, __builtin_fmaf(-g.ay, f.rx, f.nku));
-        const float w = un - den;
-        const float eq = __builtin_fmaf(__builtin_fabsf(un), E.ew, __builtin_fmaf(__builtin_fabsf(w), E.eu, E.euew));
-        const float ep = __builtin_fmaf(__builtin_fabsf(tn), E.ed, __builtin_fmaf(__builtin_fabsf(den), E.et, E.eted));
-        const float rq = __builtin_fmaf(-un, w, eq);  // < 0: u surely outside [0, 1]
-        const float rp = __builtin_fmaf(tn, den, ep); // < 0: t surely negative
-        acc = __builtin_amdgcn_alignbit(acc, ~(__float_as_uint(rq) | __float_as_uint(rp)), 31);
+    for (; s + 2 <= hi; s += 2) {
+        f32x2 rq, rp;
+        pair(s - n_circ, rq, rp);
+        acc = __builtin_amdgcn_alignbit(acc, __float_as_uint(rq.x) | __float_as_uint(rp.x), 31);
+        acc = __builtin_amdgcn_alignbit(acc, __float_as_uint(rq.y) | __float_as_uint(rp.y), 31);
     }
+    if (s < hi) { // an odd segment count ends on half a pair: the other half is the padding element
+        f32x2 rq, rp;
+        pair(s - n_circ, rq, rp);
+        acc = __builtin_amdgcn_alignbit(acc, __float_as_uint(rq.x) | __float_as_uint(rp.x), 31);
+    }
+    // keep = not drop.  The ones this puts above the collected bits are shifted out below: exactly hi - lo bits
+    // have been appended and the word is shifted up by 32 - (hi - lo).
+    acc = ~acc;
     return (acc << (32 - (hi - lo))) | force;
 }
 
@@ -253,8 +275,9 @@ RT_DEV Hit nearest_hit(SceneK S, double ox, double oy, double dx, double dy, boo
     const K_f32 c32x = (K_f32)S->c32x, c32y = (K_f32)S->c32y, c32e = (K_f32)S->c32e;
     const CircleX *cex = S->cex;
     const SegX *sex = S->sex;
-    const K_Seg32 seg32 = (K_Seg32)S->seg32;
-    const SegBounds E = { S->seg_bounds.ed, S->seg_bounds.et, S->seg_bounds.eu, S->seg_bounds.ew, S->seg_bounds.euew, S->seg_bounds.eted };
+    const K_f32 seg32 = (K_f32)S->seg32;
+    const int seg_stride = S->seg_stride;
+    const SegBounds E = { S->seg_bounds.eq, S->seg_bounds.ep };
     const int lane = lane_id();
     // outside the frame the f32 filter is proven for, every slot becomes a candidate (exact tests decide)
     bool in_range;
@@ -267,7 +290,7 @@ RT_DEV Hit nearest_hit(SceneK S, double ox, double oy, double dx, double dy, boo
         const int hi = (lo + 32 < P) ? lo + 32 : P;
         // bits below the word's last slot are shifted-in zeros; `force` may set them, so mask to the valid slots
         const uint32_t valid = 0xFFFFFFFFu << (32 - (hi - lo));
-        uint32_t mw = filter_word(n_circ, c32x, c32y, c32e, seg32, E, lo, hi, ox, oy, dx, dy, fr, force) & valid;
+        uint32_t mw = filter_word(n_circ, c32x, c32y, c32e, seg32, seg_stride, E, lo, hi, fr, force) & valid;
         if (!active) mw = 0u;
         RT_STAMP(prof, 1);
 #ifdef RT_PROF

@@ -305,6 +305,7 @@ int32_t rt2d_scene_create(rt_ctx *ctx, const rt2d_scene_desc *d, rt2d_scene **ou
     if (nsp && !d->spectra) return fail(RT_E_INVALID, "null spectra");
     const int P = nc + ns;
     const int ncp = nc + (nc & 1); // device-side circle count, padded to even for the packed f32 filter
+    const int nsp2 = ns + (ns & 1); // segment filter arrays, padded to even likewise
     std::vector<char> seen((size_t)std::max(P, 1), 0);
     auto check_pid = [&](int pid) {
         if (pid < 0 || pid >= P || seen[(size_t)pid]) return false;
@@ -375,7 +376,7 @@ int32_t rt2d_scene_create(rt_ctx *ctx, const rt2d_scene_desc *d, rt2d_scene **ou
         double *iort = c.take<double>((size_t)nior * RT_NBINS), *inv_iort = c.take<double>((size_t)nior * RT_NBINS);
         rt2d::CircleX *cex = c.take<rt2d::CircleX>(ncp);
         rt2d::SegX *sex = c.take<rt2d::SegX>(ns);
-        rt2d::Seg32 *seg32 = c.take<rt2d::Seg32>(ns);
+        float *seg32 = c.take<float>(5 * (size_t)nsp2); // sx | sy | cs | ax | ay, nsp2 floats each
         rt2d::MatDev *mats = c.take<rt2d::MatDev>(no);
         float *spectra = c.take<float>((size_t)nsp * RT_NBINS);
         if (host) {
@@ -410,8 +411,11 @@ int32_t rt2d_scene_create(rt_ctx *ctx, const rt2d_scene_desc *d, rt2d_scene **ou
                                         d->seg_nx[i], d->seg_ny[i], d->seg_pid[i], d->seg_obj[i], 0.0 };
                 const double Ax = d->seg_ax[i] - fmx, Ay = d->seg_ay[i] - fmy;
                 const double sx = d->seg_bx[i] - d->seg_ax[i], sy = d->seg_by[i] - d->seg_ay[i];
-                H(seg32)[k] = rt2d::Seg32{ (float)sx, (float)sy, (float)(Ax * sy - Ay * sx), (float)Ax, (float)Ay, { 0.0f, 0.0f, 0.0f } };
+                float *q = H(seg32) + k;
+                q[0] = (float)sx; q[nsp2] = (float)sy; q[2 * nsp2] = (float)(Ax * sy - Ay * sx); q[3 * nsp2] = (float)Ax; q[4 * nsp2] = (float)Ay;
             }
+            if (nsp2 > ns) // padding element of an odd count: read with the last segment, its result is discarded
+                for (int a = 0; a < 5; ++a) H(seg32)[(size_t)a * nsp2 + ns] = 0.0f;
             for (int i = 0; i < no; ++i) {
                 const rt2d_material &m = d->materials[i];
                 rt2d::MatDev md{};
@@ -437,8 +441,8 @@ int32_t rt2d_scene_create(rt_ctx *ctx, const rt2d_scene_desc *d, rt2d_scene **ou
         S.ior = iort; S.inv_ior = inv_iort;
         S.cex = cex;
         S.sex = sex;
-        S.seg32 = seg32;
-        S.seg_bounds = rt2d::SegBounds{ 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f }; // set per launch by filter_frame
+        S.seg32 = seg32; S.seg_stride = nsp2; S.pad2_ = 0;
+        S.seg_bounds = rt2d::SegBounds{ 0.0f, 0.0f }; // set per launch by filter_frame
         S.mats = mats; S.spectra = spectra;
     };
     rt2d::SceneDev tmp{};
@@ -527,7 +531,9 @@ int32_t filter_frame(rt_ctx *ctx, const rt2d_scene *scene, const double lo[2], c
         const double eps = 0x1.0p-24, Sx = std::max(scene->seg_extent, 0x1.0p-300);
         auto up = [](double v) { return std::nextafterf((float)v, INFINITY); };
         const double ed = 12.0 * eps * Sx, et = 16.0 * eps * B * Sx, eu = 12.0 * eps * B, ew = 20.0 * eps * (B + Sx);
-        S.seg_bounds = rt2d::SegBounds{ up(ed), up(et), up(eu), up(ew), up(eu * ew * 1.001), up(et * ed * 1.001) };
+        const double eq = 2.83 * B * ew + (2.83 * B + 1.42 * Sx) * eu + eu * ew;
+        const double ep = 4.02 * B * Sx * ed + 1.42 * Sx * et + et * ed;
+        S.seg_bounds = rt2d::SegBounds{ up(eq * 1.01), up(ep * 1.01) };
     }
     if (scene->padded_for != S.filt_M && scene->n_circles > 0) {
         // the padded radii live in the scene's blob: launches on one scene are ordered on the context's stream
