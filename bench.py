@@ -8,8 +8,8 @@ Workload at N = 1 (BASELINE.json configs[1]): the 2d stress-test scene
 recursion limit 10, f64 geometry / f32 radiance.  One step = one pass of
 `--spp` (64) samples per pixel over the whole image (rt2d_accumulate), the
 spectral radiance buffer staying resident in HBM.  The timed job is K steps,
-then — for N > 1 — one RCCL all-reduce of the per-GPU spectral buffers, then the
-resolve to sRGB.  With N GPUs every rank renders its own sample range of every
+then the resolve to sRGB; for N > 1 every rank projects its spectral sums to XYZ (a linear map), one
+RCCL all-reduce adds the 12-byte-per-pixel XYZ sums, and the encode to sRGB follows.  With N GPUs every rank renders its own sample range of every
 pixel (weak scaling: per-GPU work is fixed, total samples grow with N).
 
 1 ray = one trace_ray invocation with depth > 0 (one nearest-hit query);
@@ -80,6 +80,10 @@ def main():
     ap.add_argument("--cpu-spp", type=int, default=4, help="spp of the bounded CPU-baseline sample (0 = skip)")
     args = ap.parse_args()
 
+    if os.environ.get("RT_BENCH_WATCHDOG"):   # seconds: dump every thread's stack and exit if the run takes longer
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["RT_BENCH_WATCHDOG"]), exit=True)
+
     import torch
     import torch.distributed as dist
 
@@ -90,9 +94,15 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world_size}: launch with torch.distributed.run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU implementation")
-    torch.cuda.set_device(local_rank)
+    # RT_BENCH_BACKEND=gloo rehearses the N > 1 code path on a box with fewer GPUs than ranks (ranks then share devices)
+    backend = os.environ.get("RT_BENCH_BACKEND", "nccl")
+    device = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(device)
     if world_size > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device))
+        else:
+            dist.init_process_group(backend)
 
     import raytracer_amd as rt
     from raytracer_amd.api import params2d
@@ -100,7 +110,7 @@ def main():
 
     world = rt.World2D(args.scene, seed=1)
     stream = torch.cuda.current_stream()
-    ctx = rt.Context(local_rank, stream=stream.cuda_stream)
+    ctx = rt.Context(device, stream=stream.cuda_stream)
     scene = rt.Scene2D(ctx, world)
     W, H = args.width, args.height
     spectrum = torch.zeros(W * H * rt.NBINS, dtype=torch.float32, device="cuda")
@@ -112,10 +122,25 @@ def main():
         scene.accumulate(params2d(W, H, args.spp, args.lambda_samples, args.depth, seed=0, sample_offset=off),
                          spectrum.data_ptr())
 
+    xyz = torch.empty(W * H * 3, dtype=torch.float32, device="cuda") if world_size > 1 else None
+
+    def reduce_sum(t):
+        if backend == "nccl":
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        else:                      # rehearsal backends reduce on the host
+            h = t.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM)
+            t.copy_(h)
+
     def finish(n_steps):
+        n = total_spp(n_steps, world_size, args.spp)
         if world_size > 1:
-            dist.all_reduce(spectrum, op=dist.ReduceOp.SUM)
-        scene.resolve(spectrum.data_ptr(), W, H, total_spp(n_steps, world_size, args.spp), d_rgb_ptr=rgb.data_ptr(), to_host=False)
+            # the projection on the colour matching functions is linear: ranks exchange 12 bytes per pixel, not 380
+            scene.project_xyz(spectrum.data_ptr(), W, H, xyz.data_ptr())
+            reduce_sum(xyz)
+            scene.resolve_xyz(xyz.data_ptr(), W, H, n, d_rgb_ptr=rgb.data_ptr(), to_host=False)
+        else:
+            scene.resolve(spectrum.data_ptr(), W, H, n, d_rgb_ptr=rgb.data_ptr(), to_host=False)
 
     def barrier():
         torch.cuda.synchronize()
@@ -142,7 +167,11 @@ def main():
     st = ctx.stats()
     t = torch.tensor([dt], dtype=torch.float64, device="cuda")
     counts = torch.tensor([st["rays"], st["samples"]], dtype=torch.float64, device="cuda")
-    if world_size > 1:
+    if world_size > 1 and backend == "nccl":
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(counts, op=dist.ReduceOp.SUM)
+    elif world_size > 1:
+        t, counts = t.cpu(), counts.cpu()
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(counts, op=dist.ReduceOp.SUM)
     dt = float(t.item())
@@ -163,7 +192,7 @@ def main():
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"2d stress_test ({args.scene}, {P} primitives, seed 1) {W}x{H}, "
                                    f"{args.spp} spp/step, lambda_samples {args.lambda_samples}, depth {args.depth}; "
-                                   f"job = {args.steps} steps + spectral all-reduce + resolve",
+                                   f"job = {args.steps} steps + " + ("XYZ projection + all-reduce + encode" if world_size > 1 else "resolve"),
                        "parallelism": f"sample-batch x{world_size}", "mode": "f64 geometry / f32 radiance (parity mode)"},
             "samples_per_s": total_samples / dt,
             "rays_per_sample": total_rays / max(1.0, total_samples),

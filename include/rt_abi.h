@@ -175,6 +175,19 @@ int32_t rt2d_accumulate(rt_ctx *ctx, const rt2d_scene *scene, const rt2d_render_
 int32_t rt2d_resolve(rt_ctx *ctx, const void *d_spectrum, int32_t width, int32_t height,
                      int32_t total_spp, void *d_rgb, float *out_rgb, float *out_weight);
 
+/* The same resolve in two steps, for a sum over GPUs in between: Spectrum::to_xyz
+ * (spectrum.rs:242-262) is linear, so processes holding partial sums of one image
+ * (sample-batch sharding) exchange their XYZ sums - device f32 [W*H][3], 12 bytes
+ * per pixel - instead of their spectra.  rt2d_project_xyz writes
+ * d_xyz[pix] = sum_b d_spectrum[pix][b] * cmf[b] (no division); after the
+ * all-reduce rt2d_resolve_xyz divides by the total sample count and encodes
+ * (to_dvec3, spectrum.rs:264-278), with rt2d_resolve's outputs.  Against
+ * rt2d_resolve on the summed spectra only the order of f32 roundings differs.     */
+int32_t rt2d_project_xyz(rt_ctx *ctx, const void *d_spectrum, int32_t width, int32_t height,
+                         void *d_xyz);
+int32_t rt2d_resolve_xyz(rt_ctx *ctx, const void *d_xyz, int32_t width, int32_t height,
+                         int32_t total_spp, void *d_rgb, float *out_rgb, float *out_weight);
+
 /* ---- 2d: pixel lists ------------------------------------------------------
  * ReverseRenderer::compute_pixel (librt2d_reverse.rs:80-110) for n pixels at
  * once; out_spectrum[k][95] is the returned Spectrum of pixel (px[k], py[k]).

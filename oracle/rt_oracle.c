@@ -828,6 +828,32 @@ void rto_resolve_pixel(const float spectrum[RTO_NBINS], float rgb[3])
     }
 }
 
+/* The resolve in two steps around a sum over processes (to_xyz is linear): xyz = sum_b spectrum_sum[b] * cmf[b],
+ * then (xyz / total_spp) -> sRGB as in rto_resolve_pixel. */
+void rto_project_xyz(const float spectrum_sum[RTO_NBINS], float xyz[3])
+{
+    float x = 0.0f, y = 0.0f, z = 0.0f;
+    for (int i = 0; i < RTO_NBINS; ++i) {
+        x = x + spectrum_sum[i] * CMF[3 * i + 0];
+        y = y + spectrum_sum[i] * CMF[3 * i + 1];
+        z = z + spectrum_sum[i] * CMF[3 * i + 2];
+    }
+    xyz[0] = x; xyz[1] = y; xyz[2] = z;
+}
+
+void rto_encode_xyz(const float xyz[3], float total_spp, float rgb[3])
+{
+    const float x = xyz[0] / total_spp, y = xyz[1] / total_spp, z = xyz[2] / total_spp;
+    float lin[3];
+    lin[0] = 3.2404542f * x + -1.5371385f * y + -0.4985314f * z;
+    lin[1] = -0.9692660f * x + 1.8760108f * y + 0.0415560f * z;
+    lin[2] = 0.0556434f * x + -0.2040259f * y + 1.0572252f * z;
+    for (int k = 0; k < 3; ++k) {
+        float c = lin[k];
+        rgb[k] = (c <= 0.0031308f) ? 12.92f * c : 1.055f * powf(c, 1.0f / 2.4f) - 0.055f;
+    }
+}
+
 /* RawImage::convert_to_image(Reinhard), 2d/src/img.rs:187-218 (alpha 255) and
  * 3d/src/img.rs:126-157 (param 1, alpha 254).  `as u8` saturates, NaN -> 0.   */
 void rto_reinhard_rgba8(const float *rgb, int64_t n_pixels, float param, uint8_t alpha, uint8_t *out)

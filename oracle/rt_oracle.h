@@ -100,6 +100,8 @@ void rto_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t ou
 void rto_sincos2pi(double u, double *s, double *c);
 float rto_expf(float x);
 void rto_resolve_pixel(const float spectrum[RTO_NBINS], float rgb[3]);
+void rto_project_xyz(const float spectrum_sum[RTO_NBINS], float xyz[3]);
+void rto_encode_xyz(const float xyz[3], float total_spp, float rgb[3]);
 const float *rto_cmf_table(void); /* [95][3] */
 void rto_reinhard_rgba8(const float *rgb, int64_t n_pixels, float param, uint8_t alpha, uint8_t *out);
 

@@ -80,6 +80,8 @@ ABI = {
     "rt2d_render": (C.c_int32, [C.c_void_p, C.c_void_p, C.POINTER(RenderParams2D), c_float_p, c_float_p, c_float_p]),
     "rt2d_accumulate": (C.c_int32, [C.c_void_p, C.c_void_p, C.POINTER(RenderParams2D), C.c_void_p]),
     "rt2d_resolve": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, c_float_p, c_float_p]),
+    "rt2d_project_xyz": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
+    "rt2d_resolve_xyz": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, c_float_p, c_float_p]),
     "rt2d_compute_pixels": (C.c_int32, [C.c_void_p, C.c_void_p, C.POINTER(RenderParams2D), C.c_int64, c_int32_p, c_int32_p, c_float_p]),
     "rt2d_denoise": (C.c_int32, [C.c_void_p, C.c_void_p, C.POINTER(RenderParams2D), C.c_float, C.c_int32, C.c_float, c_float_p,
                                  c_float_p, c_float_p, C.POINTER(C.c_int64)]),

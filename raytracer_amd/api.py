@@ -273,6 +273,18 @@ class Scene2D:
                                       _ffi.ptr(weight, C.c_float)))
         return rgb, weight
 
+    def project_xyz(self, d_spectrum_ptr, width, height, d_xyz_ptr):
+        """d_xyz [H*W, 3] = the spectral sums projected on the colour matching functions (linear: sums over GPUs commute)."""
+        check(_ffi.lib().rt2d_project_xyz(self.ctx._ctx, C.c_void_p(d_spectrum_ptr), int(width), int(height), C.c_void_p(d_xyz_ptr)))
+
+    def resolve_xyz(self, d_xyz_ptr, width, height, total_spp, d_rgb_ptr=None, to_host=True):
+        rgb = np.empty((height, width, 3), np.float32) if to_host else None
+        weight = np.empty((height, width), np.float32) if to_host else None
+        check(_ffi.lib().rt2d_resolve_xyz(self.ctx._ctx, C.c_void_p(d_xyz_ptr), int(width), int(height), int(total_spp),
+                                          C.c_void_p(d_rgb_ptr) if d_rgb_ptr else None, _ffi.ptr(rgb, C.c_float),
+                                          _ffi.ptr(weight, C.c_float)))
+        return rgb, weight
+
     def compute_pixels(self, p, px, py):
         px, py = _ffi.as_i32(px), _ffi.as_i32(py)
         out = np.empty((len(px), NBINS), np.float32)

@@ -752,6 +752,42 @@ int32_t rt2d_resolve(rt_ctx *ctx, const void *d_spectrum, int32_t width, int32_t
     return RT_OK;
 }
 
+int32_t rt2d_project_xyz(rt_ctx *ctx, const void *d_spectrum, int32_t width, int32_t height, void *d_xyz)
+{
+    if (int32_t rc = ctx_bind(ctx)) return rc;
+    if (!d_spectrum || !d_xyz) return fail(RT_E_INVALID, "null device buffer");
+    if (width <= 0 || height <= 0) return fail(RT_E_INVALID, "sizes must be positive");
+    const int64_t npx = (int64_t)width * height;
+    hipLaunchKernelGGL(rtk::project_xyz_kernel, dim3((unsigned)((npx + 63) / 64)), dim3(64), 0, ctx->stream, (const float *)d_spectrum,
+                       npx, (float *)d_xyz);
+    HIP_TRY(hipGetLastError());
+    return RT_OK;
+}
+
+int32_t rt2d_resolve_xyz(rt_ctx *ctx, const void *d_xyz, int32_t width, int32_t height, int32_t total_spp, void *d_rgb,
+                         float *out_rgb, float *out_weight)
+{
+    if (int32_t rc = ctx_bind(ctx)) return rc;
+    if (!d_xyz) return fail(RT_E_INVALID, "null d_xyz");
+    if (width <= 0 || height <= 0 || total_spp <= 0) return fail(RT_E_INVALID, "sizes must be positive");
+    const int64_t npx = (int64_t)width * height;
+    float *rgb = (float *)d_rgb;
+    float *w = nullptr;
+    if (!rgb || out_weight) {
+        void *ws = nullptr;
+        if (int32_t rc = ctx_workspace(ctx, (size_t)npx * 4 * sizeof(float), &ws)) return rc;
+        if (!rgb) rgb = (float *)ws;
+        w = (float *)ws + npx * 3;
+    }
+    hipLaunchKernelGGL(rtk::encode_xyz_kernel, dim3((unsigned)((npx + rtk::BLOCK - 1) / rtk::BLOCK)), dim3(rtk::BLOCK), 0, ctx->stream,
+                       (const float *)d_xyz, npx, (float)total_spp, rgb, out_weight ? w : nullptr);
+    HIP_TRY(hipGetLastError());
+    if (out_rgb) HIP_TRY(hipMemcpyAsync(out_rgb, rgb, (size_t)npx * 3 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    if (out_weight) HIP_TRY(hipMemcpyAsync(out_weight, w, (size_t)npx * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    if (out_rgb || out_weight) HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return RT_OK;
+}
+
 int32_t rt2d_render(rt_ctx *ctx, const rt2d_scene *scene, const rt2d_render_params *p, float *out_rgb, float *out_weight,
                     float *out_spectrum)
 {

@@ -31,6 +31,8 @@ class Oracle:
         L.rto_expf.restype = C.c_float
         L.rto_expf.argtypes = [C.c_float]
         L.rto_resolve_pixel.argtypes = [fp, fp]
+        L.rto_project_xyz.argtypes = [fp, fp]
+        L.rto_encode_xyz.argtypes = [fp, C.c_float, fp]
         L.rto_cmf_table.restype = fp
         L.rto_reinhard_rgba8.argtypes = [fp, C.c_int64, C.c_float, C.c_uint8, C.POINTER(C.c_uint8)]
         L.rto2d_circle_hit.argtypes = [C.c_double] * 7 + [dp] * 5 + [C.POINTER(C.c_int)]
@@ -76,6 +78,21 @@ class Oracle:
         s = np.ascontiguousarray(spectrum, np.float32)
         out = np.zeros(3, np.float32)
         self.L.rto_resolve_pixel(_p(s, C.c_float), _p(out, C.c_float))
+        return out
+
+    def project_xyz(self, spectrum_sums):
+        """[n, 95] spectral sums -> [n, 3] XYZ sums."""
+        s = np.ascontiguousarray(spectrum_sums, np.float32).reshape(-1, NBINS)
+        out = np.zeros((s.shape[0], 3), np.float32)
+        for i in range(s.shape[0]):
+            self.L.rto_project_xyz(_p(s[i], C.c_float), _p(out[i], C.c_float))
+        return out
+
+    def encode_xyz(self, xyz, total_spp):
+        x = np.ascontiguousarray(xyz, np.float32).reshape(-1, 3)
+        out = np.zeros_like(x)
+        for i in range(x.shape[0]):
+            self.L.rto_encode_xyz(_p(x[i], C.c_float), float(total_spp), _p(out[i], C.c_float))
         return out
 
     def reinhard(self, rgb, param=1.0, alpha=255):

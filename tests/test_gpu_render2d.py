@@ -127,6 +127,36 @@ def test_resolve_and_tonemap_match_checker(gpu_ctx, oracle):
         assert np.array_equal(gpu_ctx.tonemap_reinhard(vals, param, alpha), oracle.reinhard(vals, param, alpha))
 
 
+def test_two_step_resolve_for_a_sum_over_gpus(gpu_ctx, oracle):
+    """rt2d_project_xyz + (sum over ranks) + rt2d_resolve_xyz: two partial sums of one image give the image."""
+    torch = pytest.importorskip("torch")
+    rng = np.random.default_rng(3)
+    W, H = 37, 5
+    parts = [(rng.random((H * W, 95)) * rng.random((H * W, 1)) * 3).astype(np.float32) for _ in range(2)]
+    world = rt.World2D("simple_world")
+    scene = rt.Scene2D(gpu_ctx, world)
+    total = torch.zeros(H * W * 3, device="cuda")
+    for part in parts:                                     # what each rank does before the all-reduce
+        d = torch.from_numpy(part).cuda()
+        xyz = torch.empty(H * W * 3, device="cuda")
+        scene.project_xyz(d.data_ptr(), W, H, xyz.data_ptr())
+        gpu_ctx.synchronize()
+        assert np.array_equal(xyz.cpu().numpy().reshape(-1, 3), oracle.project_xyz(part))   # same order of operations
+        total += xyz
+    rgb, weight = scene.resolve_xyz(total.data_ptr(), W, H, 12)
+    # powf of the sRGB transfer function is the platform's on both sides: last-bit differences
+    assert np.allclose(rgb.reshape(-1, 3), oracle.encode_xyz(total.cpu().numpy(), 12), rtol=1e-6, atol=1e-7)
+    assert np.all(weight == 12.0)
+    # against the one-step resolve of the summed spectra only the rounding order differs
+    both = torch.from_numpy(parts[0] + parts[1]).cuda()
+    one, _ = scene.resolve(both.data_ptr(), W, H, 12)
+    assert np.allclose(rgb, one, rtol=1e-5, atol=1e-6)
+    with pytest.raises(rt.RtError):
+        scene.resolve_xyz(total.data_ptr(), W, H, 0)
+    with pytest.raises(rt.RtError):
+        scene.project_xyz(0, W, H, total.data_ptr())
+
+
 def test_zero_depth_and_bad_params(gpu_ctx):
     world = rt.World2D("simple_world")
     scene = rt.Scene2D(gpu_ctx, world)

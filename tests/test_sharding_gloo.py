@@ -1,7 +1,8 @@
 """The multi-GPU decomposition on CPU: two processes over gloo.  Each rank renders its own
-global sample ranges (raytracer_amd.sharding, as bench.py does), the per-rank spectral
-buffers are summed with all_reduce, and the result must equal one process rendering the
-whole range.  The per-rank renderer here is the CPU checker standing in for the GPU
+global sample ranges (raytracer_amd.sharding, as bench.py does), projects its spectral sums on
+the colour matching functions, the per-rank XYZ sums are added with all_reduce and encoded, and
+the result must equal one process rendering the whole range (summing the spectra themselves is
+checked too).  The per-rank renderer here is the CPU checker standing in for the GPU
 library; what is under test is the sharding arithmetic and the reduction."""
 import os
 import socket
@@ -40,12 +41,15 @@ def _worker(rank, world_size, port, out_path):
         p = params2d(W, H, spp, 2, 10, seed=5, sample_offset=off)
         spec = oracle.render2d(world, p, threads=1)[2]
         acc += spec * np.float32(spp)          # compute_pixel returns the mean; the buffer holds the sum
+    xyz = torch.from_numpy(oracle.project_xyz(acc))    # what bench.py exchanges: 12 bytes per pixel
+    dist.all_reduce(xyz, op=dist.ReduceOp.SUM)
     t = torch.from_numpy(acc)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     if rank == 0:
         n = total_spp(steps, world_size, spp)
-        whole = oracle.render2d(world, params2d(W, H, n, 2, 10, seed=5), threads=1)[2]
-        np.savez(out_path, sharded=t.numpy() / np.float32(n), whole=whole)
+        whole_rgb, _, whole, _ = oracle.render2d(world, params2d(W, H, n, 2, 10, seed=5), threads=1)
+        np.savez(out_path, sharded=t.numpy() / np.float32(n), whole=whole,
+                 sharded_rgb=oracle.encode_xyz(xyz.numpy(), n).reshape(H, W, 3), whole_rgb=whole_rgb)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -58,6 +62,8 @@ def test_two_ranks_equal_one(tmp_path):
     r = np.load(out)
     assert r["whole"].any()
     assert np.allclose(r["sharded"], r["whole"], rtol=1e-5, atol=1e-7)
+    assert r["whole_rgb"].any()
+    assert np.allclose(r["sharded_rgb"], r["whole_rgb"], rtol=1e-5, atol=1e-6)
 
 
 def test_shard_offsets_partition_the_sample_range():
