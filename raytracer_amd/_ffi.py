@@ -115,6 +115,12 @@ HOST_ABI = {
     "rth_world2d_free": (None, [C.c_void_p]),
     "rth_scene3d_standalone": (C.c_void_p, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(Scene3DDesc)]),
     "rth_scene3d_free": (None, [C.c_void_p]),
+    "rth_world2d_decode": (C.c_void_p, [C.POINTER(C.c_uint8), C.c_uint64, C.c_int32]),
+    "rth_checkpoint_load": (C.c_void_p, [C.c_char_p]),
+    "rth_world2d_encode": (C.c_int64, [C.c_void_p, C.c_int32, c_float_p, c_float_p, C.c_int32, C.c_int32, C.POINTER(C.c_uint8),
+                                       C.c_uint64]),
+    "rth_world2d_image": (C.c_int32, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), c_float_p, c_float_p]),
+    "rth_world2d_camera": (C.c_int32, [C.c_void_p, C.POINTER(C.c_double)]),
     "rth_png_write": (C.c_int32, [C.c_char_p, C.POINTER(C.c_uint8), C.c_int32, C.c_int32]),
 }
 

@@ -26,6 +26,69 @@ class World2D:
             raise ValueError(h.rth_last_error().decode())
         self.name = name
 
+    # ---- the reference's checkpoint format (2d/src/bin/gui.rs:24-45): MessagePack as rmp-serde writes it
+    @classmethod
+    def _adopt(cls, handle, name):
+        h = _ffi.host()
+        if not handle:
+            raise ValueError(h.rth_last_error().decode())
+        self = cls.__new__(cls)
+        self._h, self.name, self.desc = handle, name, Scene2DDesc()
+        if h.rth_world2d_desc(self._h, C.byref(self.desc)) != 0:
+            raise ValueError(h.rth_last_error().decode())
+        return self
+
+    @classmethod
+    def from_bytes(cls, data, checkpoint=False):
+        """A serialised World (or, with checkpoint=True, a CheckPoint {world, raw_image})."""
+        buf = (C.c_uint8 * len(data)).from_buffer_copy(bytes(data))
+        return cls._adopt(_ffi.host().rth_world2d_decode(buf, len(data), 1 if checkpoint else 0), "bytes")
+
+    @classmethod
+    def load_checkpoint(cls, path):
+        return cls._adopt(_ffi.host().rth_checkpoint_load(str(path).encode()), str(path))
+
+    def to_bytes(self, rgb=None, weight=None):
+        """The World's bytes; with RawImage planes (rgb [H, W, 3], weight [H, W]) a whole CheckPoint."""
+        h = _ffi.host()
+        with_image = rgb is not None
+        if with_image:
+            rgb = np.ascontiguousarray(rgb, np.float32)
+            weight = np.ascontiguousarray(weight, np.float32)
+            hh, ww = weight.shape
+            assert rgb.shape == (hh, ww, 3)
+        else:
+            hh = ww = 0
+        args = (self._h, 1 if with_image else 0, _ffi.ptr(rgb, C.c_float), _ffi.ptr(weight, C.c_float), ww, hh)
+        n = h.rth_world2d_encode(*args, None, 0)
+        if n < 0:
+            raise ValueError(h.rth_last_error().decode())
+        out = (C.c_uint8 * n)()
+        if h.rth_world2d_encode(*args, out, n) != n:
+            raise ValueError(h.rth_last_error().decode())
+        return bytes(out)
+
+    def save_checkpoint(self, path, rgb, weight):
+        with open(path, "wb") as f:
+            f.write(self.to_bytes(rgb, weight))
+
+    @property
+    def image(self):
+        """(rgb [H, W, 3], weight [H, W]) of a loaded checkpoint; empty arrays for a built world."""
+        h = _ffi.host()
+        w, hh = C.c_int32(), C.c_int32()
+        h.rth_world2d_image(self._h, C.byref(w), C.byref(hh), None, None)
+        rgb = np.zeros((hh.value, w.value, 3), np.float32)
+        weight = np.zeros((hh.value, w.value), np.float32)
+        h.rth_world2d_image(self._h, C.byref(w), C.byref(hh), _ffi.ptr(rgb, C.c_float), _ffi.ptr(weight, C.c_float))
+        return rgb, weight
+
+    @property
+    def camera(self):
+        out = (C.c_double * 4)()
+        _ffi.host().rth_world2d_camera(self._h, out)
+        return (out[0], out[1]), (out[2], out[3])
+
     @property
     def n_prims(self):
         return self.desc.n_circles + self.desc.n_segments

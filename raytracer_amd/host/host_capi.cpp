@@ -6,6 +6,7 @@
 #include <memory>
 #include <string>
 
+#include "checkpoint.hpp"
 #include "png.hpp"
 #include "rt3d.hpp"
 #include "worlds.hpp"
@@ -16,6 +17,8 @@ thread_local std::string g_err;
 struct World2dHandle {
     rt2d_host::World world;
     rt2d_host::FlatScene flat;
+    rt2d_host::RawImage image{ 0, 0 }; // the RawImage of a loaded checkpoint
+    std::vector<uint8_t> encoded;      // result of the last size query of rth_world2d_encode
 };
 
 struct Scene3dHandle {
@@ -54,6 +57,104 @@ int32_t rth_world2d_desc(void *handle, rt2d_scene_desc *out)
 }
 
 void rth_world2d_free(void *handle) { delete static_cast<World2dHandle *>(handle); }
+
+// ---- the reference's checkpoint format (2d/src/bin/gui.rs:24-45), see checkpoint.hpp ----
+// A World (is_checkpoint = 0) or a CheckPoint { world, raw_image } (1) from MessagePack bytes.
+void *rth_world2d_decode(const uint8_t *data, uint64_t size, int32_t is_checkpoint)
+{
+    try {
+        if (!data) throw std::invalid_argument("null data");
+        auto h = std::make_unique<World2dHandle>();
+        if (is_checkpoint) {
+            rt2d_host::checkpoint::CheckPoint c = rt2d_host::checkpoint::decode_checkpoint(data, (size_t)size);
+            h->world = std::move(c.world);
+            h->image = std::move(c.raw_image);
+        } else {
+            h->world = rt2d_host::checkpoint::decode_world(data, (size_t)size);
+        }
+        h->flat = rt2d_host::flatten(h->world);
+        return h.release();
+    } catch (const std::exception &e) {
+        g_err = e.what();
+        return nullptr;
+    }
+}
+
+void *rth_checkpoint_load(const char *path)
+{
+    try {
+        auto h = std::make_unique<World2dHandle>();
+        rt2d_host::checkpoint::CheckPoint c = rt2d_host::checkpoint::load_checkpoint(path ? path : "");
+        h->world = std::move(c.world);
+        h->image = std::move(c.raw_image);
+        h->flat = rt2d_host::flatten(h->world);
+        return h.release();
+    } catch (const std::exception &e) {
+        g_err = e.what();
+        return nullptr;
+    }
+}
+
+// The world's MessagePack bytes (with_image = 0) or a whole CheckPoint with the given RawImage planes
+// (rgb [w*h][3], weight [w*h]).  Returns the encoded size; copies at most `cap` bytes into out.  With out = NULL
+// the bytes are kept and handed to the next call with a buffer (size query, then fetch, with the same arguments).
+int64_t rth_world2d_encode(void *handle, int32_t with_image, const float *rgb, const float *weight, int32_t w, int32_t h,
+                           uint8_t *out, uint64_t cap)
+{
+    try {
+        if (!handle) throw std::invalid_argument("null handle");
+        auto *wh = static_cast<World2dHandle *>(handle);
+        if (out && !wh->encoded.empty()) { // the size query just before encoded the same arguments
+            const std::vector<uint8_t> bytes = std::move(wh->encoded);
+            wh->encoded.clear();
+            memcpy(out, bytes.data(), (size_t)std::min<uint64_t>(cap, bytes.size()));
+            return (int64_t)bytes.size();
+        }
+        std::vector<uint8_t> bytes;
+        if (with_image) {
+            if (!rgb || !weight || w < 0 || h < 0) throw std::invalid_argument("bad image");
+            rt2d_host::checkpoint::CheckPoint c;
+            c.world = wh->world;
+            c.raw_image = rt2d_host::RawImage(w, h);
+            for (size_t i = 0; i < c.raw_image.data.size(); ++i) {
+                c.raw_image.data[i].weight = weight[i];
+                c.raw_image.data[i].value = rt2d_host::Vec3{ rgb[3 * i], rgb[3 * i + 1], rgb[3 * i + 2] };
+            }
+            bytes = rt2d_host::checkpoint::encode_checkpoint(c);
+        } else {
+            bytes = rt2d_host::checkpoint::encode_world(wh->world);
+        }
+        if (out) memcpy(out, bytes.data(), (size_t)std::min<uint64_t>(cap, bytes.size()));
+        const int64_t n = (int64_t)bytes.size();
+        if (!out) wh->encoded = std::move(bytes); // kept for the call that fetches them
+        return n;
+    } catch (const std::exception &e) {
+        g_err = e.what();
+        return -1;
+    }
+}
+
+// Size and planes of a loaded checkpoint's RawImage; rgb / weight nullable.
+int32_t rth_world2d_image(void *handle, int32_t *w, int32_t *h, float *rgb, float *weight)
+{
+    if (!handle || !w || !h) { g_err = "null argument"; return -1; }
+    const auto *wh = static_cast<World2dHandle *>(handle);
+    *w = wh->image.width; *h = wh->image.height;
+    for (size_t i = 0; i < wh->image.data.size(); ++i) {
+        if (weight) weight[i] = wh->image.data[i].weight;
+        if (rgb) { rgb[3 * i] = wh->image.data[i].value.x; rgb[3 * i + 1] = wh->image.data[i].value.y; rgb[3 * i + 2] = wh->image.data[i].value.z; }
+    }
+    return 0;
+}
+
+// camera.center, camera.size
+int32_t rth_world2d_camera(void *handle, double out[4])
+{
+    if (!handle || !out) { g_err = "null argument"; return -1; }
+    const auto &c = static_cast<World2dHandle *>(handle)->world.camera;
+    out[0] = c.center.x; out[1] = c.center.y; out[2] = c.size.x; out[3] = c.size.y;
+    return 0;
+}
 
 // Scene and camera of 3d/src/bin/standalone.rs:21-49 at the given image size.
 void *rth_scene3d_standalone(int32_t width, int32_t height, int32_t use_bvh, rt3d_scene_desc *out)
