@@ -119,7 +119,10 @@ class World2D:
             self._h = None
 
     def __del__(self):
-        self.close()
+        try:
+            self.close()
+        except Exception:   # interpreter shutdown: the module globals may be gone
+            pass
 
 
 class ArrayWorld2D:
@@ -166,7 +169,10 @@ class Standalone3D:
             self._h = None
 
     def __del__(self):
-        self.close()
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class ArrayScene3D:

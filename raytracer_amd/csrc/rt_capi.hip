@@ -1125,8 +1125,21 @@ namespace {
 
 struct BuildSphere { double c[3], r; int sid; };
 
-// Median-split BVH over sphere boxes; children of a node are adjacent; leaves hold <= 2 spheres.
+// BVH over sphere boxes; children of a node are adjacent; leaves hold <= 2 spheres.
 struct BvhBuilder {
+    static constexpr int SWEEP_MAX = 4096; // nodes up to this size are split by the surface-area heuristic
+    struct Box {
+        double lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
+        void add(const BuildSphere &s)
+        {
+            for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], s.c[a] - std::fabs(s.r)); hi[a] = std::max(hi[a], s.c[a] + std::fabs(s.r)); }
+        }
+        double half_area() const
+        {
+            const double x = hi[0] - lo[0], y = hi[1] - lo[1], z = hi[2] - lo[2];
+            return x * y + y * z + z * x;
+        }
+    };
     std::vector<BuildSphere> &sp; // tree spheres, reordered in place into leaf order
     std::vector<rt3d::BvhNode> nodes;
     int max_depth = 0;
@@ -1154,16 +1167,37 @@ struct BvhBuilder {
             nodes[(size_t)node] = nd;
             return;
         }
-        double clo[3] = { INFINITY, INFINITY, INFINITY }, chi[3] = { -INFINITY, -INFINITY, -INFINITY };
-        for (int i = first; i < first + count; ++i)
-            for (int a = 0; a < 3; ++a) { clo[a] = std::min(clo[a], sp[(size_t)i].c[a]); chi[a] = std::max(chi[a], sp[(size_t)i].c[a]); }
-        int axis = 0;
-        for (int a = 1; a < 3; ++a) if (chi[a] - clo[a] > chi[axis] - clo[axis]) axis = a;
-        const int mid = first + count / 2;
-        std::nth_element(sp.begin() + first, sp.begin() + mid, sp.begin() + first + count,
-                         [axis](const BuildSphere &x, const BuildSphere &y) {
-                             return x.c[axis] < y.c[axis] || (x.c[axis] == y.c[axis] && x.sid < y.sid);
-                         });
+        auto by_axis = [](int axis) {
+            return [axis](const BuildSphere &x, const BuildSphere &y) {
+                return x.c[axis] < y.c[axis] || (x.c[axis] == y.c[axis] && x.sid < y.sid);
+            };
+        };
+        int axis = 0, mid = first + count / 2;
+        if (count <= SWEEP_MAX) {
+            // surface-area heuristic, full sweep: for every axis sort by centre and price every split position
+            // as area(left) * n_left + area(right) * n_right; the cheapest (axis, position) wins
+            double best = INFINITY;
+            std::vector<double> right_area((size_t)count);
+            for (int a = 0; a < 3; ++a) {
+                std::sort(sp.begin() + first, sp.begin() + first + count, by_axis(a));
+                Box b;
+                for (int i = count - 1; i > 0; --i) { b.add(sp[(size_t)(first + i)]); right_area[(size_t)i] = b.half_area(); }
+                Box l;
+                for (int i = 1; i < count; ++i) {
+                    l.add(sp[(size_t)(first + i - 1)]);
+                    const double cost = l.half_area() * i + right_area[(size_t)i] * (count - i);
+                    if (cost < best) { best = cost; axis = a; mid = first + i; }
+                }
+            }
+            if (axis != 2) std::sort(sp.begin() + first, sp.begin() + first + count, by_axis(axis));
+        } else {
+            // large nodes: median of the widest centre extent
+            double clo[3] = { INFINITY, INFINITY, INFINITY }, chi[3] = { -INFINITY, -INFINITY, -INFINITY };
+            for (int i = first; i < first + count; ++i)
+                for (int a = 0; a < 3; ++a) { clo[a] = std::min(clo[a], sp[(size_t)i].c[a]); chi[a] = std::max(chi[a], sp[(size_t)i].c[a]); }
+            for (int a = 1; a < 3; ++a) if (chi[a] - clo[a] > chi[axis] - clo[axis]) axis = a;
+            std::nth_element(sp.begin() + first, sp.begin() + mid, sp.begin() + first + count, by_axis(axis));
+        }
         const int left = (int)nodes.size();
         nodes.emplace_back();
         nodes.emplace_back();
