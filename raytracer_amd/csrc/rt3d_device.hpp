@@ -45,6 +45,10 @@ struct SceneDev {
     const double *cx, *cy, *cz, *r2;
     const int32_t *sid;
     const BvhNode2 *nodes;
+    // spheres as the f32 filter sees them (see filter_word32): centre - frame centre, padded r^2 (+inf for a
+    // sphere the frame does not hold: always a candidate); n rounded up to even entries, the spare one -inf
+    const float *f32x, *f32y, *f32z, *f32e;
+    double filt_m[3], filt_B;
     double box_scale; // largest |coordinate| of a tree box
     double pos[3], p00[3], du[3], dv[3];
 };
@@ -105,18 +109,97 @@ RT_DEV uint32_t filter_word(const SceneDev &S, int lo, int hi, double ox, double
     return acc << (32 - (hi - lo));
 }
 
+// The same decision in f32, two spheres per packed instruction, for rays with | |d|^2 - 1 | <= 2^-40.
+// By Lagrange's identity the reference's discriminant is
+//   delta = h^2 - a c = a r^2 - |oc x d|^2,
+// so a sphere can only be hit when |oc x d|^2 <= a r^2.  With m the frame centre, u = o - m (U = |u|_inf, any
+// size) and v = c - m (|v_i| <= B for every sphere the frame holds):
+//   oc x d = v x d - u x d,   the second term per ray (computed in f64, rounded once),
+// each component X_i two fused steps.  Errors of a computed component (eps = 2^-24): d and v rounded to f32
+// 4 eps B, the rounded per-ray term 2 eps U, the two fused steps eps (B + 2U) + eps (2B + 2U): within
+// eps (7B + 6U) of the true value, whose size is at most 2 (B + U).  The computed |oc x d|^2 therefore exceeds
+// the true one by less than 3 x 28 eps (B + U)^2, the fused subtractions from r^2 add less than
+// 36 eps (B + U)^2 + 3 eps r^2, a = 1 +- 2^-40 moves a r^2 by 2^-40 r^2, and the reference's own f64 rounding
+// of delta is many orders below.  With the stored e = r^2 (1 + 2^-22) and the per-ray pad 128 eps (B + U)^2,
+//   g = e + pad - |oc x d|^2 >= 0   whenever the reference's delta >= 0.
+// A ray near the scene gets a thin pad; one that starts far away (a bounce off the ground plane's far side)
+// gets a wide one and more candidates, but never the f64 loop.  10 packed operations per pair + one
+// v_alignbit per sphere (the f64 form above: 15 f64 operations per sphere).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+struct FilterRay3 {
+    f32x2 dx, dy, dz;    // direction, each duplicated into both halves
+    f32x2 nkx, nky, nkz; // -(u x d)
+    f32x2 pad;           // 128 eps (B + |u|_inf)^2, rounded up
+};
+
+RT_DEV FilterRay3 filter_ray(const SceneDev &S, double ox, double oy, double oz, double dx, double dy, double dz, bool &in_range)
+{
+    const double ux = ox - S.filt_m[0], uy = oy - S.filt_m[1], uz = oz - S.filt_m[2];
+    in_range = __builtin_fabs(((dx * dx + dy * dy) + dz * dz) - 1.0) <= 0x1.0p-40;
+    const double reach = S.filt_B + __builtin_fmax(__builtin_fmax(__builtin_fabs(ux), __builtin_fabs(uy)), __builtin_fabs(uz));
+    const float padf = (float)(reach * reach * (128.0 * 0x1.0p-24)) * 1.0001f;
+    const float fx = (float)dx, fy = (float)dy, fz = (float)dz;
+    const float kx = -(float)(uy * dz - uz * dy), ky = -(float)(uz * dx - ux * dz), kz = -(float)(ux * dy - uy * dx);
+    FilterRay3 f;
+    f.dx = f32x2{ fx, fx }; f.dy = f32x2{ fy, fy }; f.dz = f32x2{ fz, fz };
+    f.nkx = f32x2{ kx, kx }; f.nky = f32x2{ ky, ky }; f.nkz = f32x2{ kz, kz };
+    f.pad = f32x2{ padf, padf };
+    return f;
+}
+
+RT_DEV uint32_t filter_word32(const SceneDev &S, int lo, int hi, const FilterRay3 &f)
+{
+    uint32_t acc = 0; // collects DROP bits (the sign of g)
+    auto pair = [&](int s) {
+        const f32x2 vx = *(const f32x2 *)(S.f32x + s), vy = *(const f32x2 *)(S.f32y + s), vz = *(const f32x2 *)(S.f32z + s);
+        const f32x2 e = *(const f32x2 *)(S.f32e + s);
+        const f32x2 xx = __builtin_elementwise_fma(f.dz, vy, __builtin_elementwise_fma(-f.dy, vz, f.nkx));
+        const f32x2 xy = __builtin_elementwise_fma(f.dx, vz, __builtin_elementwise_fma(-f.dz, vx, f.nky));
+        const f32x2 xz = __builtin_elementwise_fma(f.dy, vx, __builtin_elementwise_fma(-f.dx, vy, f.nkz));
+        return __builtin_elementwise_fma(-xx, xx, __builtin_elementwise_fma(-xy, xy, __builtin_elementwise_fma(-xz, xz, e))) + f.pad;
+    };
+    int s = lo;
+#pragma unroll 4
+    for (; s + 2 <= hi; s += 2) {
+        const f32x2 g = pair(s);
+        acc = __builtin_amdgcn_alignbit(acc, __float_as_uint(g.x), 31);
+        acc = __builtin_amdgcn_alignbit(acc, __float_as_uint(g.y), 31);
+    }
+    if (s < hi) { // odd count: the pair's second half is the padding entry
+        const f32x2 g = pair(s);
+        acc = __builtin_amdgcn_alignbit(acc, __float_as_uint(g.x), 31);
+    }
+    return ~acc << (32 - (hi - lo));
+}
+
 // Brute force over slots [first, last): same two-phase scheme as the 2d tracer.
+template <bool F32>
 RT_DEV void scan_range(const SceneDev &S, int first, int last, double ox, double oy, double oz, double dx, double dy,
                        double dz, bool active, Hit &best, int64_t &best_key)
 {
     const double a = (dx * dx + dy * dy) + dz * dz;
+    // the f32 filter serves the wave when the range is worth it and every active lane's direction is a unit vector
+    bool in_range = false;
+    FilterRay3 fr{};
+    const bool wide = F32 && last - first >= 16; // wave-uniform
+    if (wide) fr = filter_ray(S, ox, oy, oz, dx, dy, dz, in_range);
+    const bool all_in = wide && !__any(active && !in_range);
     for (int base = first; base < last; base += 256) {
         uint32_t m[8];
+        if (F32 && all_in) {
 #pragma unroll
-        for (int w = 0; w < 8; ++w) {
-            const int lo = base + 32 * w;
-            const int hi = (lo + 32 < last) ? lo + 32 : last;
-            m[w] = (lo < last) ? filter_word(S, lo, hi, ox, oy, oz, dx, dy, dz, a) : 0u;
+            for (int w = 0; w < 8; ++w) {
+                const int lo = base + 32 * w;
+                const int hi = (lo + 32 < last) ? lo + 32 : last;
+                m[w] = (lo < last) ? filter_word32(S, lo, hi, fr) : 0u;
+            }
+        } else {
+#pragma unroll
+            for (int w = 0; w < 8; ++w) {
+                const int lo = base + 32 * w;
+                const int hi = (lo + 32 < last) ? lo + 32 : last;
+                m[w] = (lo < last) ? filter_word(S, lo, hi, ox, oy, oz, dx, dy, dz, a) : 0u;
+            }
         }
         uint64_t m0 = ((uint64_t)m[0] << 32) | m[1], m1 = ((uint64_t)m[2] << 32) | m[3];
         uint64_t m2 = ((uint64_t)m[4] << 32) | m[5], m3 = ((uint64_t)m[6] << 32) | m[7];
@@ -160,6 +243,10 @@ constexpr int BVH_STACK = 32;
 // `stack` points at this lane's column of an LDS array laid out [level][2][lane]: child index and the
 // lower end of its interval (float bits), so that a popped subtree can be dropped without a visit when a
 // nearer hit has been found since it was pushed.
+// BVH = false: the reference's linear scan over every sphere (with the f32 filter ahead of the exact tests).
+// BVH = true: the spheres kept out of the tree, then the tree.  A kernel is compiled for each so that neither
+// carries the other's registers.
+template <bool BVH>
 RT_DEV Hit nearest_hit(const SceneDev &S, double ox, double oy, double oz, double dx, double dy, double dz,
                        bool active, int32_t *stack, int stack_stride)
 {
@@ -168,11 +255,11 @@ RT_DEV Hit nearest_hit(const SceneDev &S, double ox, double oy, double oz, doubl
     best.slot = -1;
     best.sid = 0x7fffffff;
     int64_t best_key = 0x7fffffffffffffffLL;
-    if (!S.use_bvh) {
-        scan_range(S, 0, S.n, ox, oy, oz, dx, dy, dz, active, best, best_key);
+    if (!BVH) {
+        scan_range<true>(S, 0, S.n, ox, oy, oz, dx, dy, dz, active, best, best_key);
         return best;
     }
-    scan_range(S, 0, S.n_always, ox, oy, oz, dx, dy, dz, active, best, best_key);
+    scan_range<false>(S, 0, S.n_always, ox, oy, oz, dx, dy, dz, active, best, best_key);
     if (S.n_nodes == 0) return best;
     const float oxf = (float)ox, oyf = (float)oy, ozf = (float)oz;
     const float pad = (__builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(oxf), __builtin_fabsf(oyf)), __builtin_fabsf(ozf)) + (float)S.box_scale) * 0x1.0p-21f;

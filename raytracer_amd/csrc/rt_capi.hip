@@ -1305,11 +1305,33 @@ int32_t rt3d_scene_create(rt_ctx *ctx, const rt3d_scene_desc *d, rt3d_scene **ou
     S.n_nodes = (int)nodes.size();
     S.box_scale = box_scale;
 
+    // frame of the f32 sphere filter (rt3d_device.hpp::filter_word32): the box of the camera position and of every
+    // sphere that is not far larger than the rest; spheres it does not hold are candidates for every ray
+    std::vector<char> framed((size_t)n, 0);
+    {
+        std::vector<double> radii((size_t)n);
+        for (int i = 0; i < n; ++i) radii[(size_t)i] = std::fabs(d->r[i]);
+        double r_med = 0.0;
+        if (n) { std::nth_element(radii.begin(), radii.begin() + n / 2, radii.end()); r_med = radii[(size_t)(n / 2)]; }
+        double lo3[3] = { pos[0], pos[1], pos[2] }, hi3[3] = { pos[0], pos[1], pos[2] };
+        for (int i = 0; i < n; ++i) {
+            if (std::fabs(d->r[i]) > 64.0 * r_med) continue;
+            framed[(size_t)i] = 1;
+            const double c[3] = { d->cx[i], d->cy[i], d->cz[i] };
+            for (int a = 0; a < 3; ++a) { lo3[a] = std::min(lo3[a], c[a] - std::fabs(d->r[i])); hi3[a] = std::max(hi3[a], c[a] + std::fabs(d->r[i])); }
+        }
+        double half = 0x1.0p-300;
+        for (int a = 0; a < 3; ++a) { S.filt_m[a] = 0.5 * (lo3[a] + hi3[a]); half = std::max(half, 0.5 * (hi3[a] - lo3[a])); }
+        S.filt_B = half * (1.0 + 0x1.0p-20);
+    }
+    const int np2 = n + (n & 1);
+
     Carver sz{ nullptr };
     auto layout = [&](Carver &c, std::vector<char> *host) {
         double *cx = c.take<double>(n), *cy = c.take<double>(n), *cz = c.take<double>(n), *r2 = c.take<double>(n);
         int32_t *sid = c.take<int32_t>(n);
         rt3d::BvhNode2 *nd = c.take<rt3d::BvhNode2>(nodes.size());
+        float *f32x = c.take<float>(np2), *f32y = c.take<float>(np2), *f32z = c.take<float>(np2), *f32e = c.take<float>(np2);
         if (host) {
             char *hb = host->data();
             auto H = [&](auto *p) { return reinterpret_cast<decltype(p)>(hb + (reinterpret_cast<char *>(p) - c.base)); };
@@ -1319,11 +1341,20 @@ int32_t rt3d_scene_create(rt_ctx *ctx, const rt3d_scene_desc *d, rt3d_scene **ou
                     H(cx)[k] = b.c[0]; H(cy)[k] = b.c[1]; H(cz)[k] = b.c[2];
                     H(r2)[k] = b.r * b.r; // radius.powi(2), rt.rs:76
                     H(sid)[k] = b.sid;
+                    const double v[3] = { b.c[0] - S.filt_m[0], b.c[1] - S.filt_m[1], b.c[2] - S.filt_m[2] };
+                    H(f32x)[k] = (float)v[0]; H(f32y)[k] = (float)v[1]; H(f32z)[k] = (float)v[2];
+                    const bool inside = framed[(size_t)b.sid] && std::fabs(v[0]) <= S.filt_B && std::fabs(v[1]) <= S.filt_B &&
+                                        std::fabs(v[2]) <= S.filt_B;
+                    const double e = b.r * b.r * (1.0 + 0x1.0p-22); // the pad is per ray
+                    H(f32e)[k] = inside ? std::nextafterf((float)e, INFINITY) : INFINITY;
+                    if (!inside) { H(f32x)[k] = 0.0f; H(f32y)[k] = 0.0f; H(f32z)[k] = 0.0f; } // keeps inf - x^2 free of inf - inf
                     ++k;
                 }
+            if (np2 > n) { H(f32x)[n] = 0.0f; H(f32y)[n] = 0.0f; H(f32z)[n] = 0.0f; H(f32e)[n] = -INFINITY; }
             if (!nodes.empty()) memcpy(H(nd), nodes.data(), sizeof(rt3d::BvhNode2) * nodes.size());
         }
         S.cx = cx; S.cy = cy; S.cz = cz; S.r2 = r2; S.sid = sid; S.nodes = nd;
+        S.f32x = f32x; S.f32y = f32y; S.f32z = f32z; S.f32e = f32e;
     };
     layout(sz, nullptr);
     const size_t bytes = sz.off + 256;
@@ -1383,8 +1414,9 @@ int32_t rt3d_accumulate(rt_ctx *ctx, const rt3d_scene *scene, const rt3d_render_
     if (int32_t rc = fold_events(ctx, 256)) return rc;
     if (int32_t rc = event_pair(ctx, &ev)) return rc;
     HIP_TRY(hipEventRecord(ev.first, ctx->stream));
-    hipLaunchKernelGGL(rtk::render3d_kernel, dim3((unsigned)tiles), dim3(rtk::BLOCK),
-                       2 * sizeof(int32_t) * rtk::BLOCK * (size_t)scene->stack_levels, ctx->stream, A);
+    const size_t stack_bytes = 2 * sizeof(int32_t) * rtk::BLOCK * (size_t)scene->stack_levels;
+    if (scene->dev.use_bvh) hipLaunchKernelGGL(rtk::render3d_kernel<true>, dim3((unsigned)tiles), dim3(rtk::BLOCK), stack_bytes, ctx->stream, A);
+    else hipLaunchKernelGGL(rtk::render3d_kernel<false>, dim3((unsigned)tiles), dim3(rtk::BLOCK), stack_bytes, ctx->stream, A);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(ev.second, ctx->stream));
     ctx->pending.push_back(ev);
@@ -1436,9 +1468,13 @@ int32_t rt3d_trace_batch(rt_ctx *ctx, const rt3d_scene *scene, int64_t n, const 
     if (int32_t rc = event_pair(ctx, &ev)) return rc;
     HIP_TRY(hipEventRecord(ev.first, ctx->stream));
     const unsigned blocks = (unsigned)((n + rtk::BLOCK - 1) / rtk::BLOCK);
-    hipLaunchKernelGGL(rtk::trace_batch3d_kernel, dim3(blocks), dim3(rtk::BLOCK),
-                       2 * sizeof(int32_t) * rtk::BLOCK * (size_t)scene->stack_levels, ctx->stream, scene->dev, n, d_o, d_d,
-                       bounce_limit, (uint32_t)seed, (uint32_t)(seed >> 32), d_rgb, d_fp, d_ft, d_nb, ctx->d_rays);
+    const size_t stack_bytes = 2 * sizeof(int32_t) * rtk::BLOCK * (size_t)scene->stack_levels;
+    if (scene->dev.use_bvh)
+        hipLaunchKernelGGL(rtk::trace_batch3d_kernel<true>, dim3(blocks), dim3(rtk::BLOCK), stack_bytes, ctx->stream, scene->dev, n, d_o, d_d,
+                           bounce_limit, (uint32_t)seed, (uint32_t)(seed >> 32), d_rgb, d_fp, d_ft, d_nb, ctx->d_rays);
+    else
+        hipLaunchKernelGGL(rtk::trace_batch3d_kernel<false>, dim3(blocks), dim3(rtk::BLOCK), stack_bytes, ctx->stream, scene->dev, n, d_o, d_d,
+                           bounce_limit, (uint32_t)seed, (uint32_t)(seed >> 32), d_rgb, d_fp, d_ft, d_nb, ctx->d_rays);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(ev.second, ctx->stream));
     ctx->pending.push_back(ev);
