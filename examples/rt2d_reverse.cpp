@@ -1,8 +1,9 @@
 // Front-end with the parameters of the reference's batch renderer (2d/src/bin/2d_reverse.rs:15-58):
 // 800x600, spp 500, recursion limit 10, 2 lambda samples, frames of sample_world(t), Reinhard{1.} PNGs.
-// Usage: rt2d_reverse [frames=1] [spp=500] [world=sample_world] [width=800] [out_prefix=out_] [loops=0] [denoise=0]
+// Usage: rt2d_reverse [frames=1] [spp=500] [world=sample_world] [width=800] [out_prefix=out_] [loops=0] [denoise=0] [device_loop=0]
 // loops > 0 renders every frame with endless_render under StopCondition::MaxLoops(loops) (librt2d_reverse.rs:424-510)
-// instead of one global_render; denoise = 1 adds the Denoiser the reference binary constructs (2d_reverse.rs:21-26).
+// instead of one global_render; denoise = 1 adds the Denoiser the reference binary constructs (2d_reverse.rs:21-26);
+// device_loop = 1 runs that loop with its state on the GPU (linear merging, see ReverseRenderer::endless_render_device).
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -22,6 +23,7 @@ int main(int argc, char **argv)
     const std::string prefix = argc > 5 ? argv[5] : "out_";
     const size_t loops = argc > 6 ? (size_t)atoi(argv[6]) : 0;
     const bool with_denoiser = argc > 7 && atoi(argv[7]) != 0;
+    const bool device_loop = argc > 8 && atoi(argv[8]) != 0;
     const int height = width * 3 / 4;
 
     ReverseRenderParams params;
@@ -47,8 +49,10 @@ int main(int argc, char **argv)
             printf("%d/%d\n", idx, frames - 1);
             const double t = (double)idx / (double)(frames > 1 ? frames : 60);
             const World world = worlds::by_name(world_name, camera, t, (uint64_t)idx, 1);
-            const RawImage raw = loops > 0 ? renderer.endless_render(world, [](size_t n, const RawImage &) { printf("loop %zu\n", n); return true; })
-                                           : renderer.global_render(world, params);
+            auto progress = [](size_t n, const RawImage &) { printf("loop %zu\n", n); return true; };
+            const RawImage raw = loops == 0 ? renderer.global_render(world, params)
+                                 : device_loop ? renderer.endless_render_device(world, progress)
+                                               : renderer.endless_render(world, progress);
             std::vector<float> rgb((size_t)width * height * 3);
             for (size_t i = 0; i < raw.data.size(); ++i) {
                 rgb[3 * i] = raw.data[i].value.x; rgb[3 * i + 1] = raw.data[i].value.y; rgb[3 * i + 2] = raw.data[i].value.z;

@@ -453,6 +453,43 @@ public:
         return merged;
     }
 
+    // The same loop with its state resident on the GPU (rt2d_progressive_*): passes merge as spectral sums and
+    // per-pixel sample counts instead of `merged + loop` on encoded colours, re-sampled pixels take
+    // floor(spp * oversampling_factor) samples, and `on_progress(loops, image)` receives sRGB(sum / count) with the
+    // sample count as weight.  One device round trip per loop: the image for the callback.
+    template <class Progress>
+    RawImage endless_render_device(const World &world, Progress on_progress)
+    {
+        bind(world);
+        const ReverseRenderParams &p = render_params;
+        const rt2d_render_params rp = abi_params(p);
+        rt2d_denoiser dn{ p.denoiser.top, p.denoiser.mask_size, p.denoiser.oversampling_factor, (int32_t)p.denoiser.passes };
+        rt2d_progressive *g = nullptr;
+        check(rt2d_progressive_create(ctx_, scene_, &rp, p.has_denoiser ? &dn : nullptr, &g));
+        const size_t n = (size_t)p.width * (size_t)p.height;
+        std::vector<float> rgb(n * 3), count(n);
+        RawImage img(p.width, p.height);
+        try {
+            for (;;) {
+                rt2d_progress st{};
+                check(rt2d_progressive_step(g, &st));
+                check(rt2d_progressive_read(g, nullptr, count.data(), rgb.data(), nullptr));
+                for (size_t i = 0; i < n; ++i) {
+                    img.data[i].weight = count[i];
+                    img.data[i].value = Vec3{ rgb[3 * i], rgb[3 * i + 1], rgb[3 * i + 2] };
+                }
+                // st.loops counts whole-image passes; the reference numbers the initial render 0
+                if (!on_progress((size_t)st.loops - 1, img)) break;
+                if (p.stop_condition.max_loops != 0 && (size_t)st.loops > p.stop_condition.max_loops) break;
+            }
+        } catch (...) {
+            rt2d_progressive_destroy(g);
+            throw;
+        }
+        rt2d_progressive_destroy(g);
+        return img;
+    }
+
     std::vector<Spectrum> compute_pixels(const ReverseRenderParams &p, const std::vector<int32_t> &px, const std::vector<int32_t> &py)
     {
         if (!scene_) throw RtError("no world bound");
