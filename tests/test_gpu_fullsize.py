@@ -76,3 +76,41 @@ def test_full_size_3d_bvh_equals_linear_scan(gpu_ctx, torch_stream):
     assert torch.allclose(imgs[0], imgs[1], rtol=1e-5, atol=1e-7)
     img = imgs[1].view(h, w, 3)
     assert not bool(img[h - 10:, :10].any()) and bool(img[: h - 10].any())  # the reference's skipped 10x10 corner
+
+
+def test_full_size_progressive_loop_with_adaptive_passes(gpu_ctx, oracle, torch_stream):
+    """configs[1] at 1080p through the device-resident loop: the sums are the plain accumulation of the same
+    sample ranges, the counts are exact, and an adaptive pass touches exactly the pixels whose count it raises."""
+    w, h, spp = 1920, 1080, 4
+    world = rt.World2D("complex_world", seed=1)
+    scene = rt.Scene2D(gpu_ctx, world)
+    p = params2d(w, h, spp, 2, 10, seed=3)
+    prog = scene.progressive(p, denoiser=(0.01, 2, 1.0, 1))
+    s1, s2 = prog.step(), prog.step()
+    assert (s1["loops"], s1["recomputed"], s1["next_sample"]) == (1, 0, spp)
+    assert s2["loops"] == 2 and s2["next_sample"] == 3 * spp
+    n_top = int(np.float32(w * h) * np.float32(0.01))
+    assert n_top <= s2["recomputed"] <= 25 * n_top
+    d_sum, d_count, d_merged, _ = prog.planes()
+    total, count, merged, loop = prog.read()
+    # the two whole passes are rt2d_accumulate's samples [0, 2 spp); re-sampled pixels hold spp more
+    plain = torch.zeros(h * w * 95, device="cuda")
+    scene.accumulate(params2d(w, h, 2 * spp, 2, 10, seed=3), plain.data_ptr())
+    plain = plain.view(h, w, 95).cpu().numpy()
+    picked = count == 3 * spp
+    inside = int(picked.sum())
+    assert 0 < inside <= s2["recomputed"] and np.all(count[~picked] == 2 * spp)
+    assert np.allclose(total[~picked], plain[~picked], rtol=1e-4, atol=1e-6)
+    # a few re-sampled pixels against the CPU checker: spp more samples from the range [2 spp, 3 spp)
+    ys, xs = np.nonzero(picked)
+    q = params2d(w, h, spp, 2, 10, seed=3, sample_offset=2 * spp)
+    for k in np.linspace(0, len(ys) - 1, 6).astype(int):
+        y, x = int(ys[k]), int(xs[k])
+        extra, _ = oracle.compute_pixel2d(world, q, x, y)
+        assert np.allclose(total[y, x] - plain[y, x], extra * spp, rtol=2e-3, atol=2e-5), (x, y)
+        want = oracle.resolve_pixel((total[y, x] / np.float32(3 * spp)).astype(np.float32))
+        assert np.allclose(merged[y, x], want, rtol=1e-4, atol=1e-5)
+    assert np.isfinite(merged).all() and np.isfinite(loop).all()
+    assert prog.image(1.0).shape == (h, w, 4)
+    prog.close()
+    scene.close()
