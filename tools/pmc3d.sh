@@ -1,10 +1,10 @@
 #!/bin/bash
 # two PMC passes over the 3d BVH render
 cd /tmp; export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
+R=$GRAFT_REPO_ROOT; EXTRA="$*"
 for pass in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE" "SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT"; do
   tag=$(echo $pass | cut -c1-12 | tr ' ' '_')
-  timeout -s KILL 120 rocprofv3 --pmc $pass --output-format csv -d $R/gpurun_out/pmc3d_$tag -- python3 $R/tools/run3d.py --spp 128 > $R/gpurun_out/pmc3d_$tag.log 2>&1 || exit 1
+  timeout -s KILL 120 rocprofv3 --pmc $pass --output-format csv -d $R/gpurun_out/pmc3d_$tag -- python3 $R/tools/run3d.py --spp 128 $EXTRA > $R/gpurun_out/pmc3d_$tag.log 2>&1 || exit 1
 done
 python3 - $R/gpurun_out <<'PY'
 import csv, glob, sys, collections
