@@ -126,10 +126,6 @@ RT_DEV uint32_t filter_word(const SceneDev &S, int lo, int hi, double ox, double
 // gets a wide one and more candidates, but never the f64 loop.  10 packed operations per pair + one
 // v_alignbit per sphere (the f64 form above: 15 f64 operations per sphere).
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-// The filter arrays are read through constant-address-space pointers, which keeps the wave-uniform loads on the
-// scalar unit (s_load) whatever else the surrounding loop does.
-typedef const f32x2 __attribute__((address_space(4))) *K_f32x2;
-typedef const float __attribute__((address_space(4))) *K_f32;
 struct FilterRay3 {
     f32x2 dx, dy, dz;    // direction, each duplicated into both halves
     f32x2 nkx, nky, nkz; // -(u x d)
@@ -155,8 +151,8 @@ RT_DEV uint32_t filter_word32(const SceneDev &S, int lo, int hi, const FilterRay
 {
     uint32_t acc = 0; // collects DROP bits (the sign of g)
     auto pair = [&](int s) {
-        const f32x2 vx = *(K_f32x2)((K_f32)S.f32x + s), vy = *(K_f32x2)((K_f32)S.f32y + s), vz = *(K_f32x2)((K_f32)S.f32z + s);
-        const f32x2 e = *(K_f32x2)((K_f32)S.f32e + s);
+        const f32x2 vx = *(const f32x2 *)(S.f32x + s), vy = *(const f32x2 *)(S.f32y + s), vz = *(const f32x2 *)(S.f32z + s);
+        const f32x2 e = *(const f32x2 *)(S.f32e + s);
         const f32x2 xx = __builtin_elementwise_fma(f.dz, vy, __builtin_elementwise_fma(-f.dy, vz, f.nkx));
         const f32x2 xy = __builtin_elementwise_fma(f.dx, vz, __builtin_elementwise_fma(-f.dz, vx, f.nky));
         const f32x2 xz = __builtin_elementwise_fma(f.dy, vx, __builtin_elementwise_fma(-f.dx, vy, f.nkz));
