@@ -213,11 +213,20 @@ int32_t rt_ctx_create(int32_t device_id, rt_ctx **out)
     rt_ctx *ctx = new (std::nothrow) rt_ctx();
     if (!ctx) return fail(RT_E_OOM, "host allocation failed");
     ctx->device = device_id;
-    HIP_TRY(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
-    ctx->stream = ctx->own_stream;
-    HIP_TRY(hipMalloc((void **)&ctx->d_rays, 2 * sizeof(unsigned long long)));
-    HIP_TRY(hipMemset(ctx->d_rays, 0, 2 * sizeof(unsigned long long)));
-    HIP_TRY(hipDeviceGetAttribute(&ctx->n_cu, hipDeviceAttributeMultiprocessorCount, ctx->device));
+    const int32_t rc = [&]() -> int32_t {
+        HIP_TRY(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
+        ctx->stream = ctx->own_stream;
+        HIP_TRY(hipMalloc((void **)&ctx->d_rays, 2 * sizeof(unsigned long long)));
+        HIP_TRY(hipMemset(ctx->d_rays, 0, 2 * sizeof(unsigned long long)));
+        HIP_TRY(hipDeviceGetAttribute(&ctx->n_cu, hipDeviceAttributeMultiprocessorCount, ctx->device));
+        return RT_OK;
+    }();
+    if (rc != RT_OK) { // nothing half-made is handed out or left behind
+        if (ctx->d_rays) (void)hipFree(ctx->d_rays);
+        if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+        delete ctx;
+        return rc;
+    }
     *out = ctx;
     return RT_OK;
 }
