@@ -181,6 +181,32 @@ def test_random_spheres_fed_batch(n, giant, use_bvh, gpu_ctx, oracle):
 
 
 @pytest.mark.parametrize("use_bvh", [False, True])
+@pytest.mark.parametrize("reach", [3e2, 1e4, 1e6])
+def test_rays_from_far_away_aimed_at_rims(reach, use_bvh, gpu_ctx, oracle):
+    """Origins far outside the scene: the linear scan's f32 filter widens its pad with the origin's distance, the BVH's
+    box test with the origin's magnitude; neither may lose a grazing hit or invent one."""
+    rng = np.random.default_rng(int(reach))
+    n = 150
+    s = random_scene3d(rng, n, True, use_bvh)
+    scene = rt.Scene3D(gpu_ctx, s)
+    m = 20_000
+    o = rng.normal(0, 1, (m, 3))
+    o *= (reach * rng.uniform(0.3, 1.0, m) / np.linalg.norm(o, axis=1))[:, None]
+    k = rng.integers(0, n - 1, m)                      # not the giant sphere
+    c = np.stack([s._a[0][k], s._a[1][k], s._a[2][k]], 1)
+    t = rng.normal(0, 1, (m, 3))
+    t -= (t * (c - o)).sum(1, keepdims=True) * (c - o) / ((c - o) ** 2).sum(1, keepdims=True)
+    t /= np.linalg.norm(t, axis=1, keepdims=True)
+    rim = c + t * s._a[3][k][:, None] * (1.0 + rng.choice([0.0, 1e-13, -1e-13, 1e-9, -1e-9, 1e-5, -1e-5, -0.5], m))[:, None]
+    d = rim - o
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    got, want = scene.trace_batch(o, d, 6, seed=3), oracle.trace_batch3d(s, o, d, 6, seed=3)
+    compare3d(got, want)
+    assert (want[1] >= 0).mean() > 0.3                 # a good share of the rays does hit something
+    scene.close()
+
+
+@pytest.mark.parametrize("use_bvh", [False, True])
 def test_random_spheres_render(use_bvh, gpu_ctx, oracle):
     rng = np.random.default_rng(4)
     s = random_scene3d(rng, 300, True, use_bvh, w=36, h=20)
