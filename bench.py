@@ -78,6 +78,9 @@ def main():
     ap.add_argument("--lambda-samples", type=int, default=2)
     ap.add_argument("--depth", type=int, default=10)
     ap.add_argument("--cpu-spp", type=int, default=4, help="spp of the bounded CPU-baseline sample (0 = skip)")
+    ap.add_argument("--merge", choices=("xyz", "spectral"), default="xyz",
+                    help="N > 1: what the ranks all-reduce - their XYZ projections (12 B/pixel, default) or the spectral "
+                         "buffers themselves (380 B/pixel); the image is the same up to f32 rounding order")
     args = ap.parse_args()
 
     if os.environ.get("RT_BENCH_WATCHDOG"):   # seconds: dump every thread's stack and exit if the run takes longer
@@ -134,12 +137,14 @@ def main():
 
     def finish(n_steps):
         n = total_spp(n_steps, world_size, args.spp)
-        if world_size > 1:
+        if world_size > 1 and args.merge == "xyz":
             # the projection on the colour matching functions is linear: ranks exchange 12 bytes per pixel, not 380
             scene.project_xyz(spectrum.data_ptr(), W, H, xyz.data_ptr())
             reduce_sum(xyz)
             scene.resolve_xyz(xyz.data_ptr(), W, H, n, d_rgb_ptr=rgb.data_ptr(), to_host=False)
         else:
+            if world_size > 1:
+                reduce_sum(spectrum)   # every rank now holds the total (the buffer is zeroed between the warm-up job and the timed one)
             scene.resolve(spectrum.data_ptr(), W, H, n, d_rgb_ptr=rgb.data_ptr(), to_host=False)
 
     def barrier():
@@ -192,7 +197,8 @@ def main():
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"2d stress_test ({args.scene}, {P} primitives, seed 1) {W}x{H}, "
                                    f"{args.spp} spp/step, lambda_samples {args.lambda_samples}, depth {args.depth}; "
-                                   f"job = {args.steps} steps + " + ("XYZ projection + all-reduce + encode" if world_size > 1 else "resolve"),
+                                   f"job = {args.steps} steps + " + (("XYZ projection + all-reduce + encode" if args.merge == "xyz" else
+                                                                      "spectral all-reduce + resolve") if world_size > 1 else "resolve"),
                        "parallelism": f"sample-batch x{world_size}", "mode": "f64 geometry / f32 radiance (parity mode)"},
             "samples_per_s": total_samples / dt,
             "rays_per_sample": total_rays / max(1.0, total_samples),
