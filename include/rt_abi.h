@@ -276,6 +276,36 @@ int32_t rt2d_progressive_read(rt2d_progressive *prog, float *out_sum, float *out
 int32_t rt2d_progressive_planes(rt2d_progressive *prog, void **d_sum, void **d_count, void **d_merged_rgb,
                                 void **d_loop_rgb);
 
+/* ---- 2d: forward light tracer ----------------------------------------------
+ * ForwardRenderer::global_render (librt2d_forward.rs:198-249): every emissive
+ * object shoots rays_per_emitter rays (the reference: 1000) from its rim
+ * (Circle::sample_out_ray, rt_common.rs:113-120), each traced for at most
+ * `depth` hit searches (the reference: 5) by ForwardRenderer::trace_ray
+ * (:66-195) at wavelength index 0 / lambda = 1.; the reference's trace_ray
+ * returns what its innermost call returns, so a path yields its last ray when
+ * that ray leaves the scene, and that ray is drawn from its origin to
+ * origin + 1000 dir with line_drawing's XiaolinWu iterator (pixel == world
+ * unit), each item added as draw_pixel(Add, value = coverage on all three
+ * channels, weight 1).  An emitter that is not a circle is RT_E_INVALID (the
+ * reference panics: sample_out_ray is todo!() for segments and strips).
+ * rt2d_forward_accumulate ADDS onto device RawImage planes (rgb f32[W*H][3],
+ * weight f32[W*H]) - one term of `merged + loop` in ForwardRenderer's
+ * endless_render (:263-296); rt2d_forward_render returns host planes that start
+ * from RawImage::new (value 0, weight 1).  out_lines (nullable) = rays drawn. */
+typedef struct rt2d_forward_params {
+    int32_t width, height;
+    int32_t rays_per_emitter;
+    int32_t depth;
+    int32_t sample_offset; /* index of the first ray of every emitter: passes that add up use disjoint ranges */
+    int32_t pad_;
+    uint64_t seed;
+} rt2d_forward_params;
+
+int32_t rt2d_forward_accumulate(rt_ctx *ctx, const rt2d_scene *scene, const rt2d_forward_params *params,
+                                void *d_rgb, void *d_weight, int64_t *out_lines);
+int32_t rt2d_forward_render(rt_ctx *ctx, const rt2d_scene *scene, const rt2d_forward_params *params,
+                            float *out_rgb, float *out_weight, int64_t *out_lines);
+
 /* ---- 2d: fed ray batches --------------------------------------------------
  * ReverseRenderer::trace_ray (librt2d_reverse.rs:112-262) for n rays:
  * radiance[k] = trace_ray(world, Ray2d{(ox,oy),(dx,dy)}, lambda_idx[k],

@@ -429,17 +429,11 @@ static double ior_at(const rto2d_material *m, double lambda)
     return m->ior_a + m->ior_b / (l * l);
 }
 
-/* ReverseRenderer::trace_ray, 2d/src/librt2d_reverse.rs:112-262 */
-static float trace_ray2d(const prep2d *pp, dv2 o, dv2 d, int lambda_idx, double lambda, int depth,
-                         int recursion_limit, const rng_stream *rs, path_info *info)
+/* objects.iter().filter_map(hit).min_by(total_cmp): first minimum wins (librt2d_reverse.rs:135-139,
+ * librt2d_forward.rs:80-84); Strip::hit = stable sort by t, first element (rt_common.rs:295-305). */
+static int scan_objects(const prep2d *pp, dv2 o, dv2 d, hit2d *out_best, int *out_obj, int *out_pid)
 {
-    if (depth == 0) return 0.0f;
     const rto2d_scene *sc = pp->sc;
-    int bounce = recursion_limit - depth;
-    info->bounces++;
-
-    /* objects.iter().filter_map(hit).min_by(total_cmp): first minimum wins (:135-139);
-     * Strip::hit = stable sort by t, first element (rt_common.rs:295-305). */
     int have = 0, best_obj = -1, best_pid = -1;
     hit2d best;
     memset(&best, 0, sizeof best);
@@ -468,6 +462,22 @@ static float trace_ray2d(const prep2d *pp, dv2 o, dv2 d, int lambda_idx, double 
             best = h; best_obj = ob; best_pid = pid; have = 1;
         }
     }
+    *out_best = best; *out_obj = best_obj; *out_pid = best_pid;
+    return have;
+}
+
+/* ReverseRenderer::trace_ray, 2d/src/librt2d_reverse.rs:112-262 */
+static float trace_ray2d(const prep2d *pp, dv2 o, dv2 d, int lambda_idx, double lambda, int depth,
+                         int recursion_limit, const rng_stream *rs, path_info *info)
+{
+    if (depth == 0) return 0.0f;
+    const rto2d_scene *sc = pp->sc;
+    int bounce = recursion_limit - depth;
+    info->bounces++;
+
+    int best_obj = -1, best_pid = -1;
+    hit2d best;
+    int have = scan_objects(pp, o, d, &best, &best_obj, &best_pid);
     if (bounce == 0) {
         info->first_prim = have ? best_pid : -1;
         info->first_t = have ? best.t : -1.0;
@@ -804,6 +814,162 @@ int rto2d_progressive_resample(const rto2d_scene *sc, const rto2d_params *p, flo
     if (out_recomputed) *out_recomputed = (int64_t)cnt;
     if (rays) *rays = total_rays;
     free(lx); free(ly);
+    prep2d_free(&pp);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------- */
+/* Forward light tracer, 2d/src/librt2d_forward.rs.  Upstream it is a stub: trace_ray hands back only what its
+ * innermost call returns, so a path yields one (ray, power, None) entry - its LAST ray, when that ray escapes
+ * the scene - or nothing; every emitter shoots 1000 rays of wavelength index 0 with `lambda = 1.`, depth 5;
+ * sample_out_ray exists for circles only (todo!() for segments and strips, rt_common.rs:278-280, 322-324).   */
+
+/* ForwardRenderer::trace_ray, :66-195.  Returns 1 when the path escapes, with its last ray. */
+static int forward_trace(const prep2d *pp, dv2 o, dv2 d, int lambda_idx, double lambda, int depth, int depth0,
+                         float power, const rng_stream *rs, dv2 *last_o, dv2 *last_d, float *last_power,
+                         uint64_t *rays)
+{
+    if (depth == 0) return 0; /* :76-78 */
+    const rto2d_scene *sc = pp->sc;
+    int bounce = depth0 - depth;
+    *rays += 1;
+    int best_obj = -1, best_pid = -1;
+    hit2d best;
+    if (!scan_objects(pp, o, d, &best, &best_obj, &best_pid)) { /* :85-87 */
+        *last_o = o; *last_d = d; *last_power = power;
+        return 1;
+    }
+    const rto2d_material *m = &sc->materials[best_obj];
+    const float *spec = sc->spectra + (size_t)m->spectrum * RTO_NBINS;
+    const double EPS = 0x1.0p-52;
+    if (best.side == 0) { /* Inside, :94-119 */
+        if (m->kind != RTO_DIELECTRIC) return 0;
+        double ior = ior_at(m, lambda);
+        dv2 p = { best.p.x + best.n.x * 10000.0 * EPS, best.p.y + best.n.y * 10000.0 * EPS };
+        dv2 nn = { -best.n.x, -best.n.y };
+        dv2 rr = refract2(d, nn, ior);
+        dv2 nd = (rr.x == 0.0 && rr.y == 0.0) ? reflect2(d, nn) : rr;
+        float new_power = power * rto_expf((float)(-best.t) * spec[lambda_idx]);
+        return forward_trace(pp, p, nd, lambda_idx, lambda, depth - 1, depth0, new_power, rs, last_o, last_d, last_power, rays);
+    }
+    switch (m->kind) { /* Outside, :120-194 */
+    case RTO_DIFFUSE: {
+        if (pp->diffuse_black[best_obj]) return 0;
+        dv2 p = { best.p.x + best.n.x * 10000.0 * EPS, best.p.y + best.n.y * 10000.0 * EPS };
+        dv2 nd = rand_hemisphere(rs, (uint32_t)bounce, best.n);
+        float new_power = spec[lambda_idx] * power;
+        if (!(new_power > 0.0f)) return 0;
+        return forward_trace(pp, p, nd, lambda_idx, lambda, depth - 1, depth0, new_power, rs, last_o, last_d, last_power, rays);
+    }
+    case RTO_REFLECTIVE: {
+        dv2 p = { best.p.x + best.n.x * 10000.0 * EPS, best.p.y + best.n.y * 10000.0 * EPS };
+        dv2 nd = reflect2(d, best.n);
+        return forward_trace(pp, p, nd, lambda_idx, lambda, depth - 1, depth0, power, rs, last_o, last_d, last_power, rays);
+    }
+    case RTO_DIELECTRIC: {
+        double ior = ior_at(m, lambda);
+        dv2 p = { best.p.x - best.n.x * 100000.0 * EPS, best.p.y - best.n.y * 100000.0 * EPS };
+        dv2 rr = refract2(d, best.n, 1.0 / ior);
+        dv2 nd = (rr.x == 0.0 && rr.y == 0.0) ? reflect2(d, best.n) : rr;
+        return forward_trace(pp, p, nd, lambda_idx, lambda, depth - 1, depth0, power, rs, last_o, last_d, last_power, rays);
+    }
+    default: /* Emissive, DirectionalEmissive: `return vec![]` */
+        return 0;
+    }
+}
+
+/* line_drawing::XiaolinWu<f64, i32> (crate line_drawing 1.0.1, a dependency that is not in the reference tree;
+ * restated from its published source): the iterator the reference draws a ray with (:222-236), each item added
+ * to the image as draw_pixel((x, y), {value: ONE * v as f32, weight: 1}, Blending::Add). */
+static void xiaolin_wu_add(double sx, double sy, double ex, double ey, int W, int H, float *rgb, float *weight)
+{
+    int steep = fabs(ey - sy) > fabs(ex - sx);
+    if (steep) { double t = sx; sx = sy; sy = t; t = ex; ex = ey; ey = t; }
+    if (sx > ex) { double t = sx; sx = ex; ex = t; t = sy; sy = ey; ey = t; }
+    double dx = ex - sx;
+    double gradient = (dx == 0.0) ? 1.0 : (ey - sy) / dx;
+    int32_t x = (int32_t)round(sx), end_x = (int32_t)round(ex);
+    double y = sy;
+    int lower = 0;
+    while (x <= end_x) {
+        double fpart = y - floor(y);
+        int32_t yi = (int32_t)y; /* NumCast: toward zero */
+        if (lower) yi += 1;
+        int px = steep ? yi : x, py = steep ? x : yi;
+        double v;
+        if (lower) {
+            lower = 0;
+            x += 1;
+            y += gradient;
+            v = fpart;
+        } else {
+            if (fpart > 0.0) lower = 1;
+            else { x += 1; y += gradient; }
+            v = 1.0 - fpart;
+        }
+        if (px >= 0 && px < W && py >= 0 && py < H) { /* pixel_to_idx, img.rs:93-99 */
+            size_t idx = (size_t)W * (size_t)py + (size_t)px;
+            float f = (float)v;
+            rgb[3 * idx] += f; rgb[3 * idx + 1] += f; rgb[3 * idx + 2] += f;
+            weight[idx] += 1.0f;
+        }
+    }
+}
+
+void rto_xiaolin_wu_add(double sx, double sy, double ex, double ey, int32_t W, int32_t H, float *rgb, float *weight)
+{
+    xiaolin_wu_add(sx, sy, ex, ey, W, H, rgb, weight);
+}
+
+/* ForwardRenderer::global_render, :198-249, ADDED onto the given RawImage planes (the reference starts from
+ * RawImage::new: value 0, weight 1).  Emitters in object order; out_lines (nullable, [n_emitters * rays][5]) =
+ * escaped flag, origin, direction of every path's last ray.  Returns -3 for an emitter that is not a circle. */
+int rto2d_forward_render(const rto2d_scene *sc, int32_t width, int32_t height, int32_t rays_per_emitter, int32_t depth,
+                         int32_t sample_offset, uint64_t seed, float *rgb, float *weight, double *out_lines,
+                         int64_t *out_n_lines, uint64_t *rays)
+{
+    if (!sc || !rgb || !weight || rays_per_emitter < 0 || depth < 0) return -1;
+    prep2d pp;
+    int rc = prep2d_init(&pp, sc);
+    if (rc) { prep2d_free(&pp); return rc; }
+    uint64_t total_rays = 0;
+    int64_t n_lines = 0, slot = 0;
+    const int lambda_idx = 0;   /* sample_emission, :211-217 */
+    const double lambda = 1.0;
+    for (int ob = 0; ob < sc->n_objects; ++ob) {
+        const rto2d_material *m = &sc->materials[ob];
+        if (m->kind != RTO_EMISSIVE && m->kind != RTO_DIRECTIONAL) continue;
+        if (!pp.shapes[ob].is_circle) { prep2d_free(&pp); return -3; }
+        int ci = pp.shapes[ob].first;
+        for (int k = 0; k < rays_per_emitter; ++k, ++slot) {
+            rng_stream rs = { { (uint32_t)seed, (uint32_t)(seed >> 32) }, 0x40000000u | (uint32_t)ob,
+                              (uint32_t)(sample_offset + k), 0u };
+            /* Circle::sample_out_ray, rt_common.rs:113-120 */
+            uint32_t w[4];
+            rng_stream gen = rs;
+            gen.c2 = 0xFFFFFFFFu;
+            rng_draw(&gen, 0u, w);
+            dv2 n;
+            rto_sincos2pi(u01(w[0], w[1]), &n.y, &n.x);
+            const double delta = 0.0001;
+            dv2 o = { sc->ccx[ci] + (sc->cr[ci] + delta) * n.x, sc->ccy[ci] + (sc->cr[ci] + delta) * n.y };
+            dv2 lo, ld;
+            float lp;
+            int escaped = forward_trace(&pp, o, n, lambda_idx, lambda, depth, depth, 1.0f, &rs, &lo, &ld, &lp, &total_rays);
+            if (out_lines) {
+                double *q = out_lines + 5 * slot;
+                q[0] = (double)escaped;
+                q[1] = escaped ? lo.x : 0.0; q[2] = escaped ? lo.y : 0.0; q[3] = escaped ? ld.x : 0.0; q[4] = escaped ? ld.y : 0.0;
+            }
+            if (escaped) {
+                ++n_lines;
+                const double t_max = 1000.0; /* hit is None, :220 */
+                xiaolin_wu_add(lo.x, lo.y, lo.x + t_max * ld.x, lo.y + t_max * ld.y, width, height, rgb, weight);
+            }
+        }
+    }
+    if (out_n_lines) *out_n_lines = n_lines;
+    if (rays) *rays = total_rays;
     prep2d_free(&pp);
     return 0;
 }

@@ -134,6 +134,12 @@ int rto2d_progressive_pass(const rto2d_scene *sc, const rto2d_params *p, int32_t
 int rto2d_progressive_resample(const rto2d_scene *sc, const rto2d_params *p, float top, int32_t mask_size,
                                int32_t n_threads, float *sum, float *count, float *merged_rgb,
                                const float *loop_rgb, int64_t *out_recomputed, uint64_t *rays);
+/* One line through line_drawing's XiaolinWu iterator, each item added as draw_pixel(Add, ONE * v, weight 1). */
+void rto_xiaolin_wu_add(double sx, double sy, double ex, double ey, int32_t W, int32_t H, float *rgb, float *weight);
+/* ForwardRenderer::global_render (2d/src/librt2d_forward.rs:198-249) added onto RawImage planes; see rt_oracle.c. */
+int rto2d_forward_render(const rto2d_scene *sc, int32_t width, int32_t height, int32_t rays_per_emitter, int32_t depth,
+                         int32_t sample_offset, uint64_t seed, float *rgb, float *weight, double *out_lines,
+                         int64_t *out_n_lines, uint64_t *rays);
 int rto2d_render(const rto2d_scene *sc, const rto2d_params *p, int32_t n_threads, float *out_rgb,
                  float *out_weight, float *out_spectrum, uint64_t *rays);
 

@@ -47,6 +47,11 @@ class Progress2D(C.Structure):
     _fields_ = [("loops", C.c_int64), ("next_sample", C.c_int64), ("recomputed", C.c_int64), ("rays", C.c_uint64)]
 
 
+class ForwardParams2D(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("rays_per_emitter", C.c_int32), ("depth", C.c_int32),
+                ("sample_offset", C.c_int32), ("pad_", C.c_int32), ("seed", C.c_uint64)]
+
+
 class Scene3DDesc(C.Structure):
     _fields_ = [("n_spheres", C.c_int32), ("use_bvh", C.c_int32),
                 ("cx", c_double_p), ("cy", c_double_p), ("cz", c_double_p), ("r", c_double_p),
@@ -97,6 +102,10 @@ ABI = {
     "rt2d_progressive_read": (C.c_int32, [C.c_void_p, c_float_p, c_float_p, c_float_p, c_float_p]),
     "rt2d_progressive_planes": (C.c_int32, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                             C.POINTER(C.c_void_p)]),
+    "rt2d_forward_accumulate": (C.c_int32, [C.c_void_p, C.c_void_p, C.POINTER(ForwardParams2D), C.c_void_p, C.c_void_p,
+                                            C.POINTER(C.c_int64)]),
+    "rt2d_forward_render": (C.c_int32, [C.c_void_p, C.c_void_p, C.POINTER(ForwardParams2D), c_float_p, c_float_p,
+                                        C.POINTER(C.c_int64)]),
     "rt2d_trace_batch": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int64, c_double_p, c_double_p, c_double_p, c_double_p,
                                      c_int32_p, C.c_int32, C.c_uint64, c_float_p, c_int32_p, c_double_p, c_int32_p]),
     "rt3d_scene_create": (C.c_int32, [C.c_void_p, C.POINTER(Scene3DDesc), C.POINTER(C.c_void_p)]),

@@ -400,6 +400,27 @@ class Scene2D:
                                           _ffi.ptr(ft, C.c_double), _ffi.ptr(nb, C.c_int32)))
         return rad, fp, ft, nb
 
+    # ---- forward light tracer (ForwardRenderer, 2d/src/librt2d_forward.rs)
+    @staticmethod
+    def forward_params(width, height, rays_per_emitter=1000, depth=5, seed=0, sample_offset=0):
+        return _ffi.ForwardParams2D(int(width), int(height), int(rays_per_emitter), int(depth), int(sample_offset), 0, int(seed))
+
+    def forward_render(self, p):
+        """ForwardRenderer::global_render: (rgb [H, W, 3], weight [H, W], lines drawn)."""
+        rgb = np.empty((p.height, p.width, 3), np.float32)
+        weight = np.empty((p.height, p.width), np.float32)
+        n = C.c_int64(0)
+        check(_ffi.lib().rt2d_forward_render(self.ctx._ctx, self._sc, C.byref(p), _ffi.ptr(rgb, C.c_float),
+                                             _ffi.ptr(weight, C.c_float), C.byref(n)))
+        return rgb, weight, n.value
+
+    def forward_accumulate(self, p, d_rgb_ptr, d_weight_ptr, count_lines=False):
+        """Adds one forward pass onto device RawImage planes; returns the number of lines drawn if asked (synchronises)."""
+        n = C.c_int64(0)
+        check(_ffi.lib().rt2d_forward_accumulate(self.ctx._ctx, self._sc, C.byref(p), C.c_void_p(d_rgb_ptr), C.c_void_p(d_weight_ptr),
+                                                 C.byref(n) if count_lines else None))
+        return n.value if count_lines else None
+
     def progressive(self, p, denoiser=None):
         """Device-resident endless_render loop: see Progressive2D."""
         return Progressive2D(self, p, denoiser)

@@ -60,6 +60,7 @@ struct SceneDev {
     // filt_M = 64 * 2^-24 filt_B^2 pads the squared radius
     double filt_mx, filt_my, filt_B, filt_M;
     const double *ior, *inv_ior; // [n_ior][95]: Ior::ior(lambda_i) and its reciprocal (rt_common.rs:442-450)
+    const double *ior_fwd, *inv_ior_fwd; // [n_ior]: the same at the forward tracer's `lambda = 1.` (librt2d_forward.rs:213)
     const CircleX *cex;
     const SegX *sex;
     // segments as the f32 filter reads them: five arrays of seg_stride floats each (the count padded to even), in
@@ -407,6 +408,9 @@ enum ShadeResult { SHADE_CONTINUE = 0, SHADE_DONE = 1, SHADE_DIFFUSE = 2 };
 // its new origin and the surface normal in (dnx, dny); its direction is then drawn
 // by rand_hemisphere_wave, which the whole wave enters together.  Every value is
 // computed with the reference's operations in the reference's order.
+// FORWARD: the forward tracer's trace_ray (librt2d_forward.rs:66-195) takes the same steps with the index of
+// refraction evaluated at its fixed `lambda = 1.`.
+template <bool FORWARD = false>
 RT_DEV ShadeResult shade(SceneK S, Path &p, const Hit &h, float &value, double &dnx, double &dny, Prof &prof)
 {
     value = 0.0f;
@@ -478,7 +482,8 @@ RT_DEV ShadeResult shade(SceneK S, Path &p, const Hit &h, float &value, double &
         bool bounce = true;
         if (diel) {
             // glam refract(dir, N, eta); eta = ior leaving (:150-152), 1/ior entering (:247-249)
-            const double eta = outside ? S->inv_ior[m.ior_row * NBINS + p.li] : S->ior[m.ior_row * NBINS + p.li];
+            const double eta = FORWARD ? (outside ? S->inv_ior_fwd[m.ior_row] : S->ior_fwd[m.ior_row])
+                                       : (outside ? S->inv_ior[m.ior_row * NBINS + p.li] : S->ior[m.ior_row * NBINS + p.li]);
             const double kk = 1.0 - eta * eta * (1.0 - ndi * ndi);
             if (kk >= 0.0) {
                 const double mm = eta * ndi + __builtin_sqrt(kk);

@@ -90,6 +90,10 @@ struct rt2d_scene {
     double seg_extent = 0.0;                             // largest |b - a| component of a segment
     mutable double padded_for = -1.0;                    // filt_M the device's c32e array currently holds
     mutable int users = 0;                               // progressive renderers bound to this scene
+    // forward tracer: emissive objects in object order; emitter_bad = first emissive object that is not a circle (-1: none)
+    std::vector<rtk::Emitter2d> emitters;
+    const rtk::Emitter2d *d_emitters = nullptr;
+    int emitter_bad = -1;
 };
 
 struct rt2d_progressive {
@@ -378,10 +382,28 @@ int32_t rt2d_scene_create(rt_ctx *ctx, const rt2d_scene_desc *d, rt2d_scene **ou
     if (P == 0) { blo[0] = blo[1] = 0.0; bhi[0] = bhi[1] = 0.0; }
     const double fmx = 0.5 * (blo[0] + bhi[0]), fmy = 0.5 * (blo[1] + bhi[1]);
 
+    // forward tracer: the emissive objects, in object order (librt2d_forward.rs:201-209)
+    std::vector<rtk::Emitter2d> emitters;
+    const rtk::Emitter2d *d_emitters = nullptr;
+    int emitter_bad = -1;
+    {
+        std::vector<int> circle_of((size_t)std::max(no, 1), -1);
+        for (int i = 0; i < nc; ++i) circle_of[(size_t)d->circle_obj[i]] = i;
+        for (int o = 0; o < no; ++o) {
+            if (d->materials[o].kind != RT_MAT_EMISSIVE && d->materials[o].kind != RT_MAT_DIRECTIONAL_EMISSIVE) continue;
+            const int ci = circle_of[(size_t)o];
+            if (ci < 0) { if (emitter_bad < 0) emitter_bad = o; continue; }
+            emitters.push_back(rtk::Emitter2d{ d->circle_cx[ci], d->circle_cy[ci], d->circle_r[ci], o, 0 });
+        }
+    }
+
     Carver sz{ nullptr };
     auto layout = [&](Carver &c, rt2d::SceneDev &S, std::vector<char> *host) {
         float *c32x = c.take<float>(ncp), *c32y = c.take<float>(ncp), *c32e = c.take<float>(ncp);
         double *iort = c.take<double>((size_t)nior * RT_NBINS), *inv_iort = c.take<double>((size_t)nior * RT_NBINS);
+        double *ior_fwd = c.take<double>((size_t)nior), *inv_ior_fwd = c.take<double>((size_t)nior);
+        rtk::Emitter2d *d_em = c.take<rtk::Emitter2d>(emitters.size());
+        d_emitters = d_em;
         rt2d::CircleX *cex = c.take<rt2d::CircleX>(ncp);
         rt2d::SegX *sex = c.take<rt2d::SegX>(ns);
         float *seg32 = c.take<float>(5 * (size_t)nsp2); // sx | sy | cs | ax | ay, nsp2 floats each
@@ -404,6 +426,14 @@ int32_t rt2d_scene_create(rt_ctx *ctx, const rt2d_scene_desc *d, rt2d_scene **ou
                 H(c32x)[nc] = 0.0f; H(c32y)[nc] = 0.0f; H(c32e)[nc] = -INFINITY;
                 H(cex)[nc] = rt2d::CircleX{ NAN, NAN, 0.0, 0x7fffffff, 0 };
             }
+            for (int k = 0; k < nior; ++k) {
+                // Ior::ior at the forward tracer's `lambda = 1.` (librt2d_forward.rs:213)
+                const double l1 = 1.0 / 1000.0;
+                const double ior1 = (iors[(size_t)k].kind == 0) ? iors[(size_t)k].a : iors[(size_t)k].a + iors[(size_t)k].b / (l1 * l1);
+                H(ior_fwd)[k] = ior1;
+                H(inv_ior_fwd)[k] = 1.0 / ior1;
+            }
+            for (size_t k = 0; k < emitters.size(); ++k) H(d_em)[k] = emitters[k];
             for (int k = 0; k < nior; ++k)
                 for (int b = 0; b < RT_NBINS; ++b) {
                     const double lambda = (double)b * 5.0 + 360.0; // spectrum.rs:185-191
@@ -447,6 +477,7 @@ int32_t rt2d_scene_create(rt_ctx *ctx, const rt2d_scene_desc *d, rt2d_scene **ou
         S.filt_mx = fmx; S.filt_my = fmy;
         S.filt_B = 0.0; S.filt_M = 0.0; // set per launch by filter_frame
         S.ior = iort; S.inv_ior = inv_iort;
+        S.ior_fwd = ior_fwd; S.inv_ior_fwd = inv_ior_fwd;
         S.cex = cex;
         S.sex = sex;
         S.seg32 = seg32; S.seg_stride = nsp2; S.pad2_ = 0;
@@ -466,6 +497,8 @@ int32_t rt2d_scene_create(rt_ctx *ctx, const rt2d_scene_desc *d, rt2d_scene **ou
     for (int i = 0; i < ns; ++i)
         sc->seg_extent = std::max(sc->seg_extent, std::max(std::fabs(d->seg_bx[i] - d->seg_ax[i]), std::fabs(d->seg_by[i] - d->seg_ay[i])));
     sc->lo[0] = blo[0]; sc->lo[1] = blo[1]; sc->hi[0] = bhi[0]; sc->hi[1] = bhi[1];
+    sc->emitters = emitters;
+    sc->emitter_bad = emitter_bad;
     hipError_t e = hipMalloc(&sc->blob, bytes);
     if (e != hipSuccess) {
         delete sc;
@@ -480,6 +513,7 @@ int32_t rt2d_scene_create(rt_ctx *ctx, const rt2d_scene_desc *d, rt2d_scene **ou
         delete sc;
         return fail(RT_E_HIP, "scene upload: %s", hipGetErrorString(e));
     }
+    sc->d_emitters = d_emitters; // set by the layout pass over the device blob
     ctx->live_scenes += 1;
     *out = sc;
     return RT_OK;
@@ -1065,6 +1099,82 @@ int32_t rt2d_progressive_planes(rt2d_progressive *g, void **d_sum, void **d_coun
     if (d_merged_rgb) *d_merged_rgb = g->merged_rgb;
     if (d_loop_rgb) *d_loop_rgb = g->loop_rgb;
     return RT_OK;
+}
+
+int32_t rt2d_forward_accumulate(rt_ctx *ctx, const rt2d_scene *scene, const rt2d_forward_params *p, void *d_rgb, void *d_weight,
+                                int64_t *out_lines)
+{
+    if (int32_t rc = ctx_bind(ctx)) return rc;
+    if (!scene || scene->ctx != ctx) return fail(RT_E_INVALID, "scene does not belong to this context");
+    if (!p || !d_rgb || !d_weight) return fail(RT_E_INVALID, "null argument");
+    if (out_lines) *out_lines = 0;
+    if (p->width <= 0 || p->height <= 0 || (int64_t)p->width * p->height > (1LL << 30)) return fail(RT_E_INVALID, "bad image size");
+    if (p->rays_per_emitter < 0 || p->rays_per_emitter > (1 << 24)) return fail(RT_E_LIMIT, "rays_per_emitter must be in 0..2^24");
+    if (p->depth < 0 || p->depth > 4095) return fail(RT_E_LIMIT, "depth must be in 0..4095");
+    if (p->sample_offset < 0 || (int64_t)p->sample_offset + p->rays_per_emitter > 0x7fffffffLL) return fail(RT_E_INVALID, "sample range out of bounds");
+    if (scene->emitter_bad >= 0)
+        return fail(RT_E_INVALID, "object %d emits but is not a circle: the reference has no sample_out_ray for segments and strips",
+                    scene->emitter_bad);
+    const int64_t n = (int64_t)scene->emitters.size() * p->rays_per_emitter;
+    if (n == 0) return RT_OK;
+    if (n > (1LL << 31)) return fail(RT_E_LIMIT, "more than 2^31 rays");
+    void *ws = nullptr;
+    if (int32_t rc = ctx_workspace(ctx, sizeof(double) * 5 * (size_t)n + 512, &ws)) return rc;
+    Carver w{ (char *)ws };
+    double *lines = w.take<double>(5 * (size_t)n);
+    unsigned long long *n_lines = w.take<unsigned long long>(1);
+    HIP_TRY(hipMemsetAsync(n_lines, 0, sizeof(unsigned long long), ctx->stream));
+    rt2d::SceneDev S{};
+    {
+        // every origin is on an emitter or a hit point: inside the scene's box
+        if (int32_t rc = filter_frame(ctx, scene, scene->lo, scene->hi, &S)) return rc;
+    }
+    std::pair<hipEvent_t, hipEvent_t> ev;
+    if (int32_t rc = fold_events(ctx, 256)) return rc;
+    if (int32_t rc = event_pair(ctx, &ev)) return rc;
+    HIP_TRY(hipEventRecord(ev.first, ctx->stream));
+    const unsigned blocks = (unsigned)((n + rtk::BLOCK - 1) / rtk::BLOCK);
+    hipLaunchKernelGGL(rtk::forward_trace_kernel, dim3(blocks), dim3(rtk::BLOCK), 0, ctx->stream, S, scene->d_emitters, n,
+                       p->rays_per_emitter, p->depth, p->sample_offset, (uint32_t)p->seed, (uint32_t)(p->seed >> 32), lines, ctx->d_rays);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(ev.second, ctx->stream));
+    ctx->pending.push_back(ev);
+    ctx->launches += 1;
+    ctx->samples += (uint64_t)n;
+    hipLaunchKernelGGL(rtk::forward_splat_kernel, dim3(blocks), dim3(rtk::BLOCK), 0, ctx->stream, lines, n, p->width, p->height,
+                       (float *)d_rgb, (float *)d_weight, n_lines);
+    HIP_TRY(hipGetLastError());
+    if (out_lines) {
+        unsigned long long c = 0;
+        HIP_TRY(hipMemcpyAsync(&c, n_lines, sizeof c, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        *out_lines = (int64_t)c;
+    }
+    return RT_OK;
+}
+
+int32_t rt2d_forward_render(rt_ctx *ctx, const rt2d_scene *scene, const rt2d_forward_params *p, float *out_rgb, float *out_weight,
+                            int64_t *out_lines)
+{
+    if (int32_t rc = ctx_bind(ctx)) return rc;
+    if (!p || !out_rgb || !out_weight) return fail(RT_E_INVALID, "null argument");
+    if (p->width <= 0 || p->height <= 0 || (int64_t)p->width * p->height > (1LL << 30)) return fail(RT_E_INVALID, "bad image size");
+    const size_t n = (size_t)p->width * (size_t)p->height;
+    // RawImage::new (img.rs:77-84): value 0, weight 1
+    std::vector<float> ones(n, 1.0f);
+    float *d = nullptr; // rgb | weight
+    hipError_t e = hipMalloc((void **)&d, sizeof(float) * n * 4);
+    if (e != hipSuccess) return fail(RT_E_OOM, "hipMalloc(%zu): %s", sizeof(float) * n * 4, hipGetErrorString(e));
+    int32_t rc = RT_OK;
+    auto step = [&](hipError_t err, const char *what) { if (rc == RT_OK && err != hipSuccess) rc = fail(RT_E_HIP, "%s: %s", what, hipGetErrorString(err)); };
+    step(hipMemsetAsync(d, 0, sizeof(float) * n * 3, ctx->stream), "clear");
+    step(hipMemcpyAsync(d + 3 * n, ones.data(), sizeof(float) * n, hipMemcpyHostToDevice, ctx->stream), "upload");
+    if (rc == RT_OK) rc = rt2d_forward_accumulate(ctx, scene, p, d, d + 3 * n, out_lines);
+    step(hipMemcpyAsync(out_rgb, d, sizeof(float) * n * 3, hipMemcpyDeviceToHost, ctx->stream), "download");
+    step(hipMemcpyAsync(out_weight, d + 3 * n, sizeof(float) * n, hipMemcpyDeviceToHost, ctx->stream), "download");
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d);
+    return rc;
 }
 
 int32_t rt2d_trace_batch(rt_ctx *ctx, const rt2d_scene *scene, int64_t n, const double *ox, const double *oy, const double *dx,

@@ -46,6 +46,9 @@ class Oracle:
                                     fp, C.POINTER(C.c_int64), C.POINTER(C.c_uint64)]
         L.rto2d_render.argtypes = [C.POINTER(Scene2DDesc), C.POINTER(OParams2D), C.c_int32, fp, fp, fp,
                                    C.POINTER(C.c_uint64)]
+        L.rto_xiaolin_wu_add.argtypes = [C.c_double] * 4 + [C.c_int32, C.c_int32, fp, fp]
+        L.rto2d_forward_render.argtypes = [C.POINTER(Scene2DDesc), C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_uint64,
+                                           fp, fp, dp, C.POINTER(C.c_int64), C.POINTER(C.c_uint64)]
         L.rto2d_progressive_pass.argtypes = [C.POINTER(Scene2DDesc), C.POINTER(OParams2D), C.c_int32, fp, fp, fp, fp,
                                              C.POINTER(C.c_uint64)]
         L.rto2d_progressive_resample.argtypes = [C.POINTER(Scene2DDesc), C.POINTER(OParams2D), C.c_float, C.c_int32, C.c_int32,
@@ -168,6 +171,26 @@ class Oracle:
                                   C.byref(rays))
         assert rc == 0, rc
         return rgb, w, key.reshape(p.height, p.width), n.value, rays.value
+
+    def xiaolin_wu(self, start, end, width, height):
+        """Coverage image [H, W] and hit-count image of one line drawn onto empty planes."""
+        rgb = np.zeros((height, width, 3), np.float32)
+        weight = np.zeros((height, width), np.float32)
+        self.L.rto_xiaolin_wu_add(float(start[0]), float(start[1]), float(end[0]), float(end[1]), int(width), int(height),
+                                  _p(rgb, C.c_float), _p(weight, C.c_float))
+        assert np.array_equal(rgb[..., 0], rgb[..., 1]) and np.array_equal(rgb[..., 0], rgb[..., 2])
+        return rgb[..., 0], weight
+
+    def forward_render(self, world, width, height, rays_per_emitter=1000, depth=5, seed=0, sample_offset=0, n_emitters_max=64):
+        """ForwardRenderer::global_render from RawImage::new: (rc, rgb, weight, lines [n, 5], n_lines, rays)."""
+        rgb = np.zeros((height, width, 3), np.float32)
+        weight = np.ones((height, width), np.float32)
+        lines = np.zeros((n_emitters_max * rays_per_emitter, 5), np.float64)
+        n, rays = C.c_int64(), C.c_uint64()
+        rc = self.L.rto2d_forward_render(C.byref(world.desc), int(width), int(height), int(rays_per_emitter), int(depth),
+                                         int(sample_offset), int(seed), _p(rgb, C.c_float), _p(weight, C.c_float),
+                                         _p(lines, C.c_double), C.byref(n), C.byref(rays))
+        return rc, rgb, weight, lines, n.value, rays.value
 
     def progressive_pass(self, world, p, sum_, count, threads=8):
         """In place on sum_ [H,W,95] and count [H,W]; returns (merged_rgb, loop_rgb, rays)."""

@@ -19,7 +19,7 @@ def declared_functions():
 def test_header_declares_the_expected_surface():
     names = declared_functions()
     for must in ("rt_ctx_create", "rt2d_scene_create", "rt2d_render", "rt2d_accumulate", "rt2d_resolve",
-                 "rt2d_project_xyz", "rt2d_resolve_xyz", "rt2d_compute_pixels", "rt2d_denoise", "rt2d_denoise_device", "rt2d_progressive_create", "rt2d_progressive_step",
+                 "rt2d_project_xyz", "rt2d_resolve_xyz", "rt2d_compute_pixels", "rt2d_denoise", "rt2d_denoise_device", "rt2d_forward_render", "rt2d_forward_accumulate", "rt2d_progressive_create", "rt2d_progressive_step",
                  "rt2d_progressive_pass", "rt2d_progressive_resample", "rt2d_progressive_image", "rt2d_progressive_read",
                  "rt2d_progressive_planes", "rt2d_progressive_destroy", "rt2d_trace_batch", "rt3d_scene_create", "rt3d_render", "rt3d_trace_batch"):
         assert must in names
