@@ -1118,31 +1118,42 @@ int32_t rt2d_forward_accumulate(rt_ctx *ctx, const rt2d_scene *scene, const rt2d
     const int64_t n = (int64_t)scene->emitters.size() * p->rays_per_emitter;
     if (n == 0) return RT_OK;
     if (n > (1LL << 31)) return fail(RT_E_LIMIT, "more than 2^31 rays");
+    // rays are traced and drawn in chunks, so the buffer of last rays between the two kernels stays small
+    const int64_t chunk = std::min<int64_t>(n, 1 << 24);
+    const int64_t npx = (int64_t)p->width * p->height;
+    Carver sizing{ nullptr };
+    sizing.take<double>(5 * (size_t)chunk); sizing.take<float>(2 * (size_t)npx); sizing.take<unsigned long long>(1);
     void *ws = nullptr;
-    if (int32_t rc = ctx_workspace(ctx, sizeof(double) * 5 * (size_t)n + 512, &ws)) return rc;
+    if (int32_t rc = ctx_workspace(ctx, sizing.off + 256, &ws)) return rc;
     Carver w{ (char *)ws };
-    double *lines = w.take<double>(5 * (size_t)n);
+    double *lines = w.take<double>(5 * (size_t)chunk);
+    float *cov = w.take<float>(2 * (size_t)npx);
     unsigned long long *n_lines = w.take<unsigned long long>(1);
     HIP_TRY(hipMemsetAsync(n_lines, 0, sizeof(unsigned long long), ctx->stream));
+    HIP_TRY(hipMemsetAsync(cov, 0, sizeof(float) * 2 * (size_t)npx, ctx->stream));
     rt2d::SceneDev S{};
-    {
-        // every origin is on an emitter or a hit point: inside the scene's box
-        if (int32_t rc = filter_frame(ctx, scene, scene->lo, scene->hi, &S)) return rc;
+    if (int32_t rc = filter_frame(ctx, scene, scene->lo, scene->hi, &S)) return rc; // every origin lies in the scene's box
+    for (int64_t first = 0; first < n; first += chunk) {
+        const int64_t m = std::min<int64_t>(chunk, n - first);
+        std::pair<hipEvent_t, hipEvent_t> ev;
+        if (int32_t rc = fold_events(ctx, 256)) return rc;
+        if (int32_t rc = event_pair(ctx, &ev)) return rc;
+        HIP_TRY(hipEventRecord(ev.first, ctx->stream));
+        const unsigned blocks = (unsigned)((m + rtk::BLOCK - 1) / rtk::BLOCK);
+        hipLaunchKernelGGL(rtk::forward_trace_kernel, dim3(blocks), dim3(rtk::BLOCK), 0, ctx->stream, S, scene->d_emitters, first, m,
+                           p->rays_per_emitter, p->depth, p->sample_offset, (uint32_t)p->seed, (uint32_t)(p->seed >> 32), lines,
+                           ctx->d_rays);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(ev.second, ctx->stream));
+        ctx->pending.push_back(ev);
+        ctx->launches += 1;
+        hipLaunchKernelGGL(rtk::forward_splat_kernel, dim3(blocks), dim3(rtk::BLOCK), 0, ctx->stream, lines, m, p->width, p->height, cov,
+                           n_lines);
+        HIP_TRY(hipGetLastError());
     }
-    std::pair<hipEvent_t, hipEvent_t> ev;
-    if (int32_t rc = fold_events(ctx, 256)) return rc;
-    if (int32_t rc = event_pair(ctx, &ev)) return rc;
-    HIP_TRY(hipEventRecord(ev.first, ctx->stream));
-    const unsigned blocks = (unsigned)((n + rtk::BLOCK - 1) / rtk::BLOCK);
-    hipLaunchKernelGGL(rtk::forward_trace_kernel, dim3(blocks), dim3(rtk::BLOCK), 0, ctx->stream, S, scene->d_emitters, n,
-                       p->rays_per_emitter, p->depth, p->sample_offset, (uint32_t)p->seed, (uint32_t)(p->seed >> 32), lines, ctx->d_rays);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(ev.second, ctx->stream));
-    ctx->pending.push_back(ev);
-    ctx->launches += 1;
     ctx->samples += (uint64_t)n;
-    hipLaunchKernelGGL(rtk::forward_splat_kernel, dim3(blocks), dim3(rtk::BLOCK), 0, ctx->stream, lines, n, p->width, p->height,
-                       (float *)d_rgb, (float *)d_weight, n_lines);
+    hipLaunchKernelGGL(rtk::forward_merge_kernel, dim3((unsigned)((npx + rtk::BLOCK - 1) / rtk::BLOCK)), dim3(rtk::BLOCK), 0, ctx->stream,
+                       cov, npx, (float *)d_rgb, (float *)d_weight);
     HIP_TRY(hipGetLastError());
     if (out_lines) {
         unsigned long long c = 0;

@@ -10,6 +10,7 @@
 //   2d/src/worlds.rs        the scene builders
 //   2d/src/img.rs           PixelData, RawImage, Blending, ToneMappingMethod
 //   2d/src/librt2d_reverse.rs  ReverseRenderParams, ReverseRenderer
+//   2d/src/librt2d_forward.rs  ForwardRenderParams, ForwardRenderer
 #pragma once
 
 #include <array>
@@ -531,6 +532,98 @@ private:
     rt2d_scene *scene_ = nullptr;
     const World *bound_ = nullptr;
     size_t bound_objects_ = 0;
+};
+
+// ---- librt2d_forward.rs -----------------------------------------------------
+// librt2d_forward.rs:43-50.  recursion_limit and lambda_samples are carried as in the reference, which reads
+// neither: global_render uses 1000 rays per emitter and depth 5 (:219-221).
+struct ForwardRenderParams {
+    int32_t width = 800, height = 600;
+    StopCondition stop_condition;
+    size_t recursion_limit = 2;
+    size_t lambda_samples = 1;
+    // not in the reference (its generator is unseeded)
+    uint64_t seed = 0;
+};
+
+class ForwardRenderer {
+public:
+    static constexpr int32_t RAYS_PER_EMITTER = 1000, DEPTH = 5; // librt2d_forward.rs:219-221
+
+    explicit ForwardRenderer(const ForwardRenderParams &p, int device = 0) : render_params_(p)
+    {
+        check(rt_ctx_create(device, &ctx_));
+    }
+    ~ForwardRenderer()
+    {
+        if (scene_) rt2d_scene_destroy(scene_);
+        if (ctx_) rt_ctx_destroy(ctx_);
+    }
+    ForwardRenderer(const ForwardRenderer &) = delete;
+    ForwardRenderer &operator=(const ForwardRenderer &) = delete;
+    rt_ctx *context() const { return ctx_; }
+
+    // librt2d_forward.rs:198-249.  Successive calls shoot different rays (the reference draws fresh random numbers).
+    RawImage global_render(const World &world)
+    {
+        bind(world);
+        rt2d_forward_params fp{};
+        fp.width = render_params_.width; fp.height = render_params_.height;
+        fp.rays_per_emitter = RAYS_PER_EMITTER; fp.depth = DEPTH;
+        fp.sample_offset = next_ray_; fp.seed = render_params_.seed;
+        next_ray_ += RAYS_PER_EMITTER;
+        const size_t n = (size_t)fp.width * (size_t)fp.height;
+        std::vector<float> rgb(n * 3), weight(n);
+        check(rt2d_forward_render(ctx_, scene_, &fp, rgb.data(), weight.data(), nullptr));
+        RawImage img(fp.width, fp.height);
+        for (size_t i = 0; i < n; ++i) {
+            img.data[i].weight = weight[i];
+            img.data[i].value = Vec3{ rgb[3 * i], rgb[3 * i + 1], rgb[3 * i + 2] };
+        }
+        return img;
+    }
+
+    // librt2d_forward.rs:252-350 without the channels and the heatmap file: `merged + loop` (img.rs:257-274) per loop.
+    template <class Progress>
+    RawImage endless_render(const World &world, Progress on_progress)
+    {
+        RawImage merged = global_render(world);
+        (void)on_progress((size_t)0, merged);
+        for (size_t loop_n = 1;;) {
+            if (!on_progress(loop_n, merged)) break;
+            const RawImage loop_image = global_render(world);
+            RawImage sum(merged.width, merged.height);
+            for (size_t i = 0; i < sum.data.size(); ++i)
+                sum.data[i].value = Vec3{ merged.data[i].value.x + loop_image.data[i].value.x, merged.data[i].value.y + loop_image.data[i].value.y,
+                                          merged.data[i].value.z + loop_image.data[i].value.z };
+            merged = sum;
+            ++loop_n;
+            if (render_params_.stop_condition.max_loops != 0 && loop_n > render_params_.stop_condition.max_loops) break;
+        }
+        return merged;
+    }
+
+private:
+    void bind(const World &world)
+    {
+        if (scene_ && bound_ == &world && bound_objects_ == world.objects.size()) return;
+        if (scene_) { rt2d_scene_destroy(scene_); scene_ = nullptr; }
+        const FlatScene f = flatten(world);
+        const rt2d_scene_desc d = f.desc();
+        check(rt2d_scene_create(ctx_, &d, &scene_));
+        bound_ = &world;
+        bound_objects_ = world.objects.size();
+    }
+    static void check(int32_t rc)
+    {
+        if (rc != RT_OK) throw RtError(std::string("rt_abi call failed (") + std::to_string(rc) + "): " + rt_last_error());
+    }
+    ForwardRenderParams render_params_;
+    rt_ctx *ctx_ = nullptr;
+    rt2d_scene *scene_ = nullptr;
+    const World *bound_ = nullptr;
+    size_t bound_objects_ = 0;
+    int32_t next_ray_ = 0;
 };
 
 } // namespace rt2d_host
