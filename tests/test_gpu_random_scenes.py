@@ -218,3 +218,33 @@ def test_random_spheres_render(use_bvh, gpu_ctx, oracle):
     assert gpu_ctx.stats()["rays"] == orays
     assert np.allclose(img, oimg, rtol=1e-5, atol=1e-7)
     scene.close()
+
+
+def test_empty_worlds(gpu_ctx, oracle):
+    """No primitives at all: every ray misses (2d: radiance 0; 3d: the background), on both sides."""
+    z = np.zeros(0)
+    world = rt.ArrayWorld2D(dict(circle_cx=z, circle_cy=z, circle_r=z, circle_obj=z, circle_pid=z, seg_ax=z, seg_ay=z, seg_bx=z,
+                                 seg_by=z, seg_nx=z, seg_ny=z, seg_obj=z, seg_pid=z, materials=np.zeros((0, 7)),
+                                 spectra=np.zeros((0, 95), np.float32)))
+    scene = rt.Scene2D(gpu_ctx, world)
+    p = params2d(20, 12, 3, 2, 10, seed=1)
+    gpu_ctx.reset_stats()
+    rgb, weight, spec = scene.global_render(p, want_spectrum=True)
+    st = gpu_ctx.stats()
+    assert not spec.any() and not rgb.any() and np.all(weight == 3)
+    assert st["rays"] == 20 * 12 * 3 * 2 == st["samples"]          # one hit search per sample, all misses
+    orgb, _, ospec, orays = oracle.render2d(world, p)
+    assert not ospec.any() and orays == st["rays"]
+    rays = (np.array([1.0, 2.0]), np.array([3.0, 4.0]), np.array([1.0, 0.0]), np.array([0.0, 1.0]), np.zeros(2, np.int32))
+    rad, fp, ft, nb = scene.trace_batch(*rays, depth=4)
+    assert not rad.any() and np.all(fp == -1) and np.all(nb == 1)
+    rgbf, wf, n = scene.forward_render(scene.forward_params(16, 16, 10, 5))   # no emitters: nothing to draw
+    assert n == 0 and not rgbf.any() and np.all(wf == 1.0)
+    scene.close()
+    for use_bvh in (False, True):
+        s3 = rt.ArrayScene3D(z, z, z, z, (0.0, 0.0, 0.0), (0.0, 0.0, -1.0), (0.0, 1.0, 0.0), 1.0, 24, 16, use_bvh=use_bvh)
+        sc3 = rt.Scene3D(gpu_ctx, s3)
+        img = sc3.render(params3d(2, 5, seed=1))
+        oimg, _ = oracle.render3d(s3, params3d(2, 5, seed=1))
+        assert np.allclose(img, oimg, rtol=1e-6, atol=1e-7) and img.any()
+        sc3.close()
