@@ -1,5 +1,9 @@
-import time, sys
-sys.path.insert(0, "/root/repo")
+"""Time the host-pointer entry rt2d_render (= global_render) on the headline workload."""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import raytracer_amd as rt
 from raytracer_amd.api import params2d
 ctx = rt.Context(0)
