@@ -6,8 +6,11 @@
  * the 2d crate's `ReverseRenderer::{global_render, render_column, compute_pixel,
  * trace_ray}` (2d/src/librt2d_reverse.rs:80-302) and the 3d crate's
  * `World::{render, compute_pixel, trace_ray}` (3d/src/rt.rs:216-273) keep their
- * Rust signatures and run on the GPU.  Every declaration cites the reference
- * code it replaces (paths relative to the reference root).
+ * Rust signatures and run on the GPU - and, one step out from that path, its
+ * callers: `ReverseRenderer::denoise` and `endless_render`
+ * (librt2d_reverse.rs:337-510) and `ForwardRenderer::global_render`
+ * (librt2d_forward.rs:198-249).  Every declaration cites the reference code it
+ * replaces (paths relative to the reference root).
  *
  * Conventions
  *  - plain pointers and sizes only; every function returns 0 on success or a
