@@ -33,6 +33,11 @@ typedef const double __attribute__((address_space(4))) *K_f64;
 typedef const float __attribute__((address_space(4))) *K_f32;
 struct SegX;
 typedef const SegX __attribute__((address_space(4))) *K_SegX;
+// Two segments as the f32 filter reads them, each field holding the value of both: s = b - a, cs = A x s,
+// A = a - frame centre.  One record per pair keeps the loop's scalar side to one address and two loads; five
+// separate arrays cost five loads and ten address instructions per pair, more than the pair's vector work.
+struct SegPair { f32x2 sx, sy, cs, ax, ay; };
+typedef const SegPair __attribute__((address_space(4))) *K_SegPair;
 // Margins of the segment filter for one launch (see filter_word).
 struct SegBounds { float eq, ep; };
 
@@ -63,10 +68,8 @@ struct SceneDev {
     const double *ior_fwd, *inv_ior_fwd; // [n_ior]: the same at the forward tracer's `lambda = 1.` (librt2d_forward.rs:213)
     const CircleX *cex;
     const SegX *sex;
-    // segments as the f32 filter reads them: five arrays of seg_stride floats each (the count padded to even), in
-    // the order sx, sy (s = b - a), cs = A x s, ax, ay (A = a - frame centre)
-    const float *seg32;
-    int32_t seg_stride, pad2_;
+    // segments as the f32 filter reads them: one 40-byte record per PAIR of segments (the count padded to even)
+    const SegPair *segp;
     SegBounds seg_bounds; // set per launch with the frame
     const MatDev *mats;
     const float *spectra;
@@ -195,7 +198,7 @@ RT_DEV FilterRay filter_ray(SceneK S, double ox, double oy, double dx, double dy
     return f;
 }
 
-RT_DEV uint32_t filter_word(int n_circ, K_f32 c32x, K_f32 c32y, K_f32 c32e, K_f32 seg32, int seg_stride, const SegBounds &E, int lo, int hi,
+RT_DEV uint32_t filter_word(int n_circ, K_f32 c32x, K_f32 c32y, K_f32 c32e, K_SegPair segp, const SegBounds &E, int lo, int hi,
                             const FilterRay &f, uint32_t force)
 {
     uint32_t acc = 0;
@@ -215,12 +218,9 @@ RT_DEV uint32_t filter_word(int n_circ, K_f32 c32x, K_f32 c32y, K_f32 c32e, K_f3
     // two segments per packed instruction as well (the segment arrays are padded to an even count; the first
     // segment slot, n_circ, is even).  Drop bits again: sign(rq) | sign(rp).
     const int s_lo = lo > n_circ ? lo : n_circ;
-    const K_f32 a_sx = seg32, a_sy = seg32 + seg_stride, a_cs = seg32 + 2 * seg_stride, a_ax = seg32 + 3 * seg_stride,
-                a_ay = seg32 + 4 * seg_stride;
     const f32x2 eq = { E.eq, E.eq }, ep = { E.ep, E.ep };
-    auto pair = [&](int k, f32x2 &rq, f32x2 &rp) {
-        const f32x2 sx = *(K_f32x2)(a_sx + k), sy = *(K_f32x2)(a_sy + k), cs = *(K_f32x2)(a_cs + k);
-        const f32x2 ax = *(K_f32x2)(a_ax + k), ay = *(K_f32x2)(a_ay + k);
+    auto pair = [&](K_SegPair gp, f32x2 &rq, f32x2 &rp) {
+        const f32x2 sx = gp->sx, sy = gp->sy, cs = gp->cs, ax = gp->ax, ay = gp->ay;
         const f32x2 den = __builtin_elementwise_fma(-f.ndx, sy, -(f.dy * sx));                              // d x s
         const f32x2 tn = __builtin_elementwise_fma(f.uy, sx, __builtin_elementwise_fma(f.nux, sy, cs));     // (A - U) x s
         const f32x2 un = __builtin_elementwise_fma(ax, f.dy, __builtin_elementwise_fma(ay, f.ndx, f.nku));  // (A - U) x d
@@ -229,16 +229,17 @@ RT_DEV uint32_t filter_word(int n_circ, K_f32 c32x, K_f32 c32y, K_f32 c32e, K_f3
         rp = __builtin_elementwise_fma(tn, den, ep); // < 0: t surely negative
     };
     int s = s_lo;
+    K_SegPair gp = segp + ((s_lo - n_circ) >> 1);
 #pragma unroll 2
-    for (; s + 2 <= hi; s += 2) {
+    for (; s + 2 <= hi; s += 2, ++gp) {
         f32x2 rq, rp;
-        pair(s - n_circ, rq, rp);
+        pair(gp, rq, rp);
         acc = __builtin_amdgcn_alignbit(acc, __float_as_uint(rq.x) | __float_as_uint(rp.x), 31);
         acc = __builtin_amdgcn_alignbit(acc, __float_as_uint(rq.y) | __float_as_uint(rp.y), 31);
     }
     if (s < hi) { // an odd segment count ends on half a pair: the other half is the padding element
         f32x2 rq, rp;
-        pair(s - n_circ, rq, rp);
+        pair(gp, rq, rp);
         acc = __builtin_amdgcn_alignbit(acc, __float_as_uint(rq.x) | __float_as_uint(rp.x), 31);
     }
     // keep = not drop.  The ones this puts above the collected bits are shifted out below: exactly hi - lo bits
@@ -276,8 +277,7 @@ RT_DEV Hit nearest_hit(SceneK S, double ox, double oy, double dx, double dy, boo
     const K_f32 c32x = (K_f32)S->c32x, c32y = (K_f32)S->c32y, c32e = (K_f32)S->c32e;
     const CircleX *cex = S->cex;
     const SegX *sex = S->sex;
-    const K_f32 seg32 = (K_f32)S->seg32;
-    const int seg_stride = S->seg_stride;
+    const K_SegPair segp = (K_SegPair)S->segp;
     const SegBounds E = { S->seg_bounds.eq, S->seg_bounds.ep };
     const int lane = lane_id();
     // outside the frame the f32 filter is proven for, every slot becomes a candidate (exact tests decide)
@@ -291,7 +291,7 @@ RT_DEV Hit nearest_hit(SceneK S, double ox, double oy, double dx, double dy, boo
         const int hi = (lo + 32 < P) ? lo + 32 : P;
         // bits below the word's last slot are shifted-in zeros; `force` may set them, so mask to the valid slots
         const uint32_t valid = 0xFFFFFFFFu << (32 - (hi - lo));
-        uint32_t mw = filter_word(n_circ, c32x, c32y, c32e, seg32, seg_stride, E, lo, hi, fr, force) & valid;
+        uint32_t mw = filter_word(n_circ, c32x, c32y, c32e, segp, E, lo, hi, fr, force) & valid;
         if (!active) mw = 0u;
         RT_STAMP(prof, 1);
 #ifdef RT_PROF

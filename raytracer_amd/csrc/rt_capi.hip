@@ -410,7 +410,7 @@ int32_t rt2d_scene_create(rt_ctx *ctx, const rt2d_scene_desc *d, rt2d_scene **ou
         d_emitters = d_em;
         rt2d::CircleX *cex = c.take<rt2d::CircleX>(ncp);
         rt2d::SegX *sex = c.take<rt2d::SegX>(ns);
-        float *seg32 = c.take<float>(5 * (size_t)nsp2); // sx | sy | cs | ax | ay, nsp2 floats each
+        rt2d::SegPair *segp = c.take<rt2d::SegPair>((size_t)nsp2 / 2);
         rt2d::MatDev *mats = c.take<rt2d::MatDev>(no);
         float *spectra = c.take<float>((size_t)nsp * RT_NBINS);
         if (host) {
@@ -453,11 +453,14 @@ int32_t rt2d_scene_create(rt_ctx *ctx, const rt2d_scene_desc *d, rt2d_scene **ou
                                         d->seg_nx[i], d->seg_ny[i], d->seg_pid[i], d->seg_obj[i], 0.0 };
                 const double Ax = d->seg_ax[i] - fmx, Ay = d->seg_ay[i] - fmy;
                 const double sx = d->seg_bx[i] - d->seg_ax[i], sy = d->seg_by[i] - d->seg_ay[i];
-                float *q = H(seg32) + k;
-                q[0] = (float)sx; q[nsp2] = (float)sy; q[2 * nsp2] = (float)(Ax * sy - Ay * sx); q[3 * nsp2] = (float)Ax; q[4 * nsp2] = (float)Ay;
+                rt2d::SegPair &q = H(segp)[k >> 1];
+                const int h = k & 1;
+                q.sx[h] = (float)sx; q.sy[h] = (float)sy; q.cs[h] = (float)(Ax * sy - Ay * sx); q.ax[h] = (float)Ax; q.ay[h] = (float)Ay;
             }
-            if (nsp2 > ns) // padding element of an odd count: read with the last segment, its result is discarded
-                for (int a = 0; a < 5; ++a) H(seg32)[(size_t)a * nsp2 + ns] = 0.0f;
+            if (nsp2 > ns) { // padding half of an odd count: read with the last segment, its result is discarded
+                rt2d::SegPair &q = H(segp)[ns >> 1];
+                q.sx[1] = q.sy[1] = q.cs[1] = q.ax[1] = q.ay[1] = 0.0f;
+            }
             for (int i = 0; i < no; ++i) {
                 const rt2d_material &m = d->materials[i];
                 rt2d::MatDev md{};
@@ -484,7 +487,7 @@ int32_t rt2d_scene_create(rt_ctx *ctx, const rt2d_scene_desc *d, rt2d_scene **ou
         S.ior_fwd = ior_fwd; S.inv_ior_fwd = inv_ior_fwd;
         S.cex = cex;
         S.sex = sex;
-        S.seg32 = seg32; S.seg_stride = nsp2; S.pad2_ = 0;
+        S.segp = segp;
         S.seg_bounds = rt2d::SegBounds{ 0.0f, 0.0f }; // set per launch by filter_frame
         S.mats = mats; S.spectra = spectra;
     };
