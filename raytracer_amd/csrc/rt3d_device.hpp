@@ -38,6 +38,11 @@ struct BvhNode2 {
     int32_t pad_[2];
 };
 
+// Two spheres as the f32 filter reads them, each field holding the value of both (one scalar load and one address
+// per pair: with four separate arrays the loop's scalar side weighs as much as its vector side).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+struct SpherePair { f32x2 vx, vy, vz, e; };
+
 struct SceneDev {
     int32_t n, n_always, n_nodes, width, height, use_bvh;
     // slot order: the `n_always` spheres tested on every ray first (those too
@@ -45,9 +50,9 @@ struct SceneDev {
     const double *cx, *cy, *cz, *r2;
     const int32_t *sid;
     const BvhNode2 *nodes;
-    // spheres as the f32 filter sees them (see filter_word32): centre - frame centre, padded r^2 (+inf for a
-    // sphere the frame does not hold: always a candidate); n rounded up to even entries, the spare one -inf
-    const float *f32x, *f32y, *f32z, *f32e;
+    // spheres as the f32 filter sees them (see filter_word32), one record per pair of slots: centre - frame centre,
+    // padded r^2 (+inf for a sphere the frame does not hold: always a candidate); an odd count's spare half is -inf
+    const SpherePair *f32p;
     double filt_m[3], filt_B;
     double box_scale; // largest |coordinate| of a tree box
     double pos[3], p00[3], du[3], dv[3];
@@ -125,7 +130,6 @@ RT_DEV uint32_t filter_word(const SceneDev &S, int lo, int hi, double ox, double
 // A ray near the scene gets a thin pad; one that starts far away (a bounce off the ground plane's far side)
 // gets a wide one and more candidates, but never the f64 loop.  10 packed operations per pair + one
 // v_alignbit per sphere (the f64 form above: 15 f64 operations per sphere).
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 struct FilterRay3 {
     f32x2 dx, dy, dz;    // direction, each duplicated into both halves
     f32x2 nkx, nky, nkz; // -(u x d)
@@ -150,23 +154,23 @@ RT_DEV FilterRay3 filter_ray(const SceneDev &S, double ox, double oy, double oz,
 RT_DEV uint32_t filter_word32(const SceneDev &S, int lo, int hi, const FilterRay3 &f)
 {
     uint32_t acc = 0; // collects DROP bits (the sign of g)
-    auto pair = [&](int s) {
-        const f32x2 vx = *(const f32x2 *)(S.f32x + s), vy = *(const f32x2 *)(S.f32y + s), vz = *(const f32x2 *)(S.f32z + s);
-        const f32x2 e = *(const f32x2 *)(S.f32e + s);
+    auto pair = [&](const SpherePair *q) {
+        const f32x2 vx = q->vx, vy = q->vy, vz = q->vz, e = q->e;
         const f32x2 xx = __builtin_elementwise_fma(f.dz, vy, __builtin_elementwise_fma(-f.dy, vz, f.nkx));
         const f32x2 xy = __builtin_elementwise_fma(f.dx, vz, __builtin_elementwise_fma(-f.dz, vx, f.nky));
         const f32x2 xz = __builtin_elementwise_fma(f.dy, vx, __builtin_elementwise_fma(-f.dx, vy, f.nkz));
         return __builtin_elementwise_fma(-xx, xx, __builtin_elementwise_fma(-xy, xy, __builtin_elementwise_fma(-xz, xz, e))) + f.pad;
     };
     int s = lo;
+    const SpherePair *q = S.f32p + (lo >> 1); // lo is a multiple of 32
 #pragma unroll 4
-    for (; s + 2 <= hi; s += 2) {
-        const f32x2 g = pair(s);
+    for (; s + 2 <= hi; s += 2, ++q) {
+        const f32x2 g = pair(q);
         acc = __builtin_amdgcn_alignbit(acc, __float_as_uint(g.x), 31);
         acc = __builtin_amdgcn_alignbit(acc, __float_as_uint(g.y), 31);
     }
     if (s < hi) { // odd count: the pair's second half is the padding entry
-        const f32x2 g = pair(s);
+        const f32x2 g = pair(q);
         acc = __builtin_amdgcn_alignbit(acc, __float_as_uint(g.x), 31);
     }
     return ~acc << (32 - (hi - lo));

@@ -1477,7 +1477,7 @@ int32_t rt3d_scene_create(rt_ctx *ctx, const rt3d_scene_desc *d, rt3d_scene **ou
         double *cx = c.take<double>(n), *cy = c.take<double>(n), *cz = c.take<double>(n), *r2 = c.take<double>(n);
         int32_t *sid = c.take<int32_t>(n);
         rt3d::BvhNode2 *nd = c.take<rt3d::BvhNode2>(nodes.size());
-        float *f32x = c.take<float>(np2), *f32y = c.take<float>(np2), *f32z = c.take<float>(np2), *f32e = c.take<float>(np2);
+        rt3d::SpherePair *f32p = c.take<rt3d::SpherePair>((size_t)np2 / 2);
         if (host) {
             char *hb = host->data();
             auto H = [&](auto *p) { return reinterpret_cast<decltype(p)>(hb + (reinterpret_cast<char *>(p) - c.base)); };
@@ -1488,19 +1488,25 @@ int32_t rt3d_scene_create(rt_ctx *ctx, const rt3d_scene_desc *d, rt3d_scene **ou
                     H(r2)[k] = b.r * b.r; // radius.powi(2), rt.rs:76
                     H(sid)[k] = b.sid;
                     const double v[3] = { b.c[0] - S.filt_m[0], b.c[1] - S.filt_m[1], b.c[2] - S.filt_m[2] };
-                    H(f32x)[k] = (float)v[0]; H(f32y)[k] = (float)v[1]; H(f32z)[k] = (float)v[2];
                     const bool inside = framed[(size_t)b.sid] && std::fabs(v[0]) <= S.filt_B && std::fabs(v[1]) <= S.filt_B &&
                                         std::fabs(v[2]) <= S.filt_B;
                     const double e = b.r * b.r * (1.0 + 0x1.0p-22); // the pad is per ray
-                    H(f32e)[k] = inside ? std::nextafterf((float)e, INFINITY) : INFINITY;
-                    if (!inside) { H(f32x)[k] = 0.0f; H(f32y)[k] = 0.0f; H(f32z)[k] = 0.0f; } // keeps inf - x^2 free of inf - inf
+                    rt3d::SpherePair &q = H(f32p)[k >> 1];
+                    const int h = k & 1;
+                    // outside the frame: a candidate for every ray (zero centre keeps inf - x^2 free of inf - inf)
+                    q.vx[h] = inside ? (float)v[0] : 0.0f; q.vy[h] = inside ? (float)v[1] : 0.0f; q.vz[h] = inside ? (float)v[2] : 0.0f;
+                    q.e[h] = inside ? std::nextafterf((float)e, INFINITY) : INFINITY;
                     ++k;
                 }
-            if (np2 > n) { H(f32x)[n] = 0.0f; H(f32y)[n] = 0.0f; H(f32z)[n] = 0.0f; H(f32e)[n] = -INFINITY; }
+            if (np2 > n) {
+                rt3d::SpherePair &q = H(f32p)[n >> 1];
+                q.vx[1] = q.vy[1] = q.vz[1] = 0.0f;
+                q.e[1] = -INFINITY;
+            }
             if (!nodes.empty()) memcpy(H(nd), nodes.data(), sizeof(rt3d::BvhNode2) * nodes.size());
         }
         S.cx = cx; S.cy = cy; S.cz = cz; S.r2 = r2; S.sid = sid; S.nodes = nd;
-        S.f32x = f32x; S.f32y = f32y; S.f32z = f32z; S.f32e = f32e;
+        S.f32p = f32p;
     };
     layout(sz, nullptr);
     const size_t bytes = sz.off + 256;
