@@ -33,6 +33,9 @@ typedef const double __attribute__((address_space(4))) *K_f64;
 typedef const float __attribute__((address_space(4))) *K_f32;
 struct SegX;
 typedef const SegX __attribute__((address_space(4))) *K_SegX;
+// Two circles as the f32 filter reads them (see filter_word): centre - frame centre and the padded r^2 of both.
+struct CirclePair { f32x2 vx, vy, e; };
+typedef const CirclePair __attribute__((address_space(4))) *K_CirclePair;
 // Two segments as the f32 filter reads them, each field holding the value of both: s = b - a, cs = A x s,
 // A = a - frame centre.  One record per pair keeps the loop's scalar side to one address and two loads; five
 // separate arrays cost five loads and ten address instructions per pair, more than the pair's vector work.
@@ -60,7 +63,7 @@ struct SceneDev {
     int32_t n_circ, n_seg, n_obj, pad_; // n_circ is even: an odd circle count is padded with a circle nothing can hit
     // circles as the f32 filter sees them (see filter_word): c32x/c32y = centre - frame centre (filt_mx, filt_my)
     // rounded to f32; c32e = r^2 (1 + 2^-22) + filt_M rounded up, rewritten by pad_radii_kernel when filt_M changes
-    const float *c32x, *c32y, *c32e;
+    const CirclePair *c32;
     // filter frame, set per launch: the filter is proven for |origin - centre|_inf <= filt_B and | |dir|^2 - 1 | <= 2^-40;
     // filt_M = 64 * 2^-24 filt_B^2 pads the squared radius
     double filt_mx, filt_my, filt_B, filt_M;
@@ -198,18 +201,17 @@ RT_DEV FilterRay filter_ray(SceneK S, double ox, double oy, double dx, double dy
     return f;
 }
 
-RT_DEV uint32_t filter_word(int n_circ, K_f32 c32x, K_f32 c32y, K_f32 c32e, K_SegPair segp, const SegBounds &E, int lo, int hi,
+RT_DEV uint32_t filter_word(int n_circ, K_CirclePair c32, K_SegPair segp, const SegBounds &E, int lo, int hi,
                             const FilterRay &f, uint32_t force)
 {
     uint32_t acc = 0;
     const int c_end = hi < n_circ ? hi : n_circ;
     // two circles per packed f32 instruction (v_pk_fma_f32): the circle count is padded to even
     // and word boundaries are even, so a pair never straddles a word
+    K_CirclePair cp = c32 + (lo >> 1);
 #pragma unroll 4
-    for (int s = lo; s < c_end; s += 2) {
-        const f32x2 vx = *(K_f32x2)(c32x + s);
-        const f32x2 vy = *(K_f32x2)(c32y + s);
-        const f32x2 e = *(K_f32x2)(c32e + s);
+    for (int s = lo; s < c_end; s += 2, ++cp) {
+        const f32x2 vx = cp->vx, vy = cp->vy, e = cp->e;
         const f32x2 x = __builtin_elementwise_fma(f.dy, vx, __builtin_elementwise_fma(f.ndx, vy, f.kc)); // d x (u - v)
         const f32x2 g = __builtin_elementwise_fma(x, -x, e);                                             // padded r^2 - X^2
         acc = __builtin_amdgcn_alignbit(acc, __float_as_uint(g.x), 31); // collects the sign of g: set = drop
@@ -274,7 +276,7 @@ RT_DEV Hit nearest_hit(SceneK S, double ox, double oy, double dx, double dy, boo
     // read once per call: inside the loops below the compiler would fetch them again for every word
     const int n_circ = S->n_circ;
     const int P = n_circ + S->n_seg;
-    const K_f32 c32x = (K_f32)S->c32x, c32y = (K_f32)S->c32y, c32e = (K_f32)S->c32e;
+    const K_CirclePair c32 = (K_CirclePair)S->c32;
     const CircleX *cex = S->cex;
     const SegX *sex = S->sex;
     const K_SegPair segp = (K_SegPair)S->segp;
@@ -291,7 +293,7 @@ RT_DEV Hit nearest_hit(SceneK S, double ox, double oy, double dx, double dy, boo
         const int hi = (lo + 32 < P) ? lo + 32 : P;
         // bits below the word's last slot are shifted-in zeros; `force` may set them, so mask to the valid slots
         const uint32_t valid = 0xFFFFFFFFu << (32 - (hi - lo));
-        uint32_t mw = filter_word(n_circ, c32x, c32y, c32e, segp, E, lo, hi, fr, force) & valid;
+        uint32_t mw = filter_word(n_circ, c32, segp, E, lo, hi, fr, force) & valid;
         if (!active) mw = 0u;
         RT_STAMP(prof, 1);
 #ifdef RT_PROF

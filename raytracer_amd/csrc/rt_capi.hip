@@ -403,7 +403,7 @@ int32_t rt2d_scene_create(rt_ctx *ctx, const rt2d_scene_desc *d, rt2d_scene **ou
 
     Carver sz{ nullptr };
     auto layout = [&](Carver &c, rt2d::SceneDev &S, std::vector<char> *host) {
-        float *c32x = c.take<float>(ncp), *c32y = c.take<float>(ncp), *c32e = c.take<float>(ncp);
+        rt2d::CirclePair *c32 = c.take<rt2d::CirclePair>((size_t)ncp / 2);
         double *iort = c.take<double>((size_t)nior * RT_NBINS), *inv_iort = c.take<double>((size_t)nior * RT_NBINS);
         double *ior_fwd = c.take<double>((size_t)nior), *inv_ior_fwd = c.take<double>((size_t)nior);
         rtk::Emitter2d *d_em = c.take<rtk::Emitter2d>(emitters.size());
@@ -421,13 +421,15 @@ int32_t rt2d_scene_create(rt_ctx *ctx, const rt2d_scene_desc *d, rt2d_scene **ou
                 const double r2 = d->circle_r[i] * d->circle_r[i]; // r.powi(2), rt_common.rs:76,83
                 H(cex)[k] = rt2d::CircleX{ d->circle_cx[i], d->circle_cy[i], r2, d->circle_pid[i], d->circle_obj[i] };
                 const float vx = (float)(d->circle_cx[i] - fmx), vy = (float)(d->circle_cy[i] - fmy);
-                H(c32x)[k] = vx;
-                H(c32y)[k] = vy;
-                H(c32e)[k] = INFINITY; // written by pad_radii_kernel before the first launch
+                rt2d::CirclePair &q = H(c32)[k >> 1];
+                q.vx[k & 1] = vx;
+                q.vy[k & 1] = vy;
+                q.e[k & 1] = INFINITY; // written by pad_radii_kernel before the first launch
             }
             if (ncp > nc) {
                 // padding circle: the filter always drops it (g = -inf) and the exact test can never accept a NaN centre
-                H(c32x)[nc] = 0.0f; H(c32y)[nc] = 0.0f; H(c32e)[nc] = -INFINITY;
+                rt2d::CirclePair &q = H(c32)[nc >> 1];
+                q.vx[1] = 0.0f; q.vy[1] = 0.0f; q.e[1] = -INFINITY;
                 H(cex)[nc] = rt2d::CircleX{ NAN, NAN, 0.0, 0x7fffffff, 0 };
             }
             for (int k = 0; k < nior; ++k) {
@@ -480,7 +482,7 @@ int32_t rt2d_scene_create(rt_ctx *ctx, const rt2d_scene_desc *d, rt2d_scene **ou
             if (nsp) memcpy(H(spectra), d->spectra, sizeof(float) * (size_t)nsp * RT_NBINS);
         }
         S.n_circ = ncp; S.n_seg = ns; S.n_obj = no; S.pad_ = 0;
-        S.c32x = c32x; S.c32y = c32y; S.c32e = c32e;
+        S.c32 = c32;
         S.filt_mx = fmx; S.filt_my = fmy;
         S.filt_B = 0.0; S.filt_M = 0.0; // set per launch by filter_frame
         S.ior = iort; S.inv_ior = inv_iort;
@@ -587,7 +589,7 @@ int32_t filter_frame(rt_ctx *ctx, const rt2d_scene *scene, const double lo[2], c
     if (scene->padded_for != S.filt_M && scene->n_circles > 0) {
         // the padded radii live in the scene's blob: launches on one scene are ordered on the context's stream
         hipLaunchKernelGGL(rtk::pad_radii_kernel, dim3((unsigned)((scene->n_circles + rtk::BLOCK - 1) / rtk::BLOCK)), dim3(rtk::BLOCK),
-                           0, ctx->stream, S.cex, scene->n_circles, S.filt_M, const_cast<float *>(S.c32e));
+                           0, ctx->stream, S.cex, scene->n_circles, S.filt_M, const_cast<rt2d::CirclePair *>(S.c32));
         HIP_TRY(hipGetLastError());
         scene->padded_for = S.filt_M;
     }
