@@ -201,6 +201,21 @@ RT_DEV FilterRay filter_ray(SceneK S, double ox, double oy, double dx, double dy
     return f;
 }
 
+// A word whose 32 slots are all circles: the same test with no bounds to compute, 16 pairs straight through.
+RT_DEV uint32_t filter_circle_word(K_CirclePair cp, const FilterRay &f, uint32_t force)
+{
+    uint32_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const f32x2 vx = cp[k].vx, vy = cp[k].vy, e = cp[k].e;
+        const f32x2 x = __builtin_elementwise_fma(f.dy, vx, __builtin_elementwise_fma(f.ndx, vy, f.kc));
+        const f32x2 g = __builtin_elementwise_fma(x, -x, e);
+        acc = __builtin_amdgcn_alignbit(acc, __float_as_uint(g.x), 31);
+        acc = __builtin_amdgcn_alignbit(acc, __float_as_uint(g.y), 31);
+    }
+    return ~acc | force;
+}
+
 RT_DEV uint32_t filter_word(int n_circ, K_CirclePair c32, K_SegPair segp, const SegBounds &E, int lo, int hi,
                             const FilterRay &f, uint32_t force)
 {
@@ -293,7 +308,8 @@ RT_DEV Hit nearest_hit(SceneK S, double ox, double oy, double dx, double dy, boo
         const int hi = (lo + 32 < P) ? lo + 32 : P;
         // bits below the word's last slot are shifted-in zeros; `force` may set them, so mask to the valid slots
         const uint32_t valid = 0xFFFFFFFFu << (32 - (hi - lo));
-        uint32_t mw = filter_word(n_circ, c32, segp, E, lo, hi, fr, force) & valid;
+        uint32_t mw = (hi <= n_circ && hi - lo == 32) ? filter_circle_word(c32 + (lo >> 1), fr, force)
+                                                      : filter_word(n_circ, c32, segp, E, lo, hi, fr, force) & valid;
         if (!active) mw = 0u;
         RT_STAMP(prof, 1);
 #ifdef RT_PROF
