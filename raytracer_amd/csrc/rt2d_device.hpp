@@ -216,6 +216,26 @@ RT_DEV uint32_t filter_circle_word(K_CirclePair cp, const FilterRay &f, uint32_t
     return ~acc | force;
 }
 
+// A word whose 32 slots are all segments, likewise.
+RT_DEV uint32_t filter_segment_word(K_SegPair gp, const SegBounds &E, const FilterRay &f, uint32_t force)
+{
+    uint32_t acc = 0;
+    const f32x2 eq = { E.eq, E.eq }, ep = { E.ep, E.ep };
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const f32x2 sx = gp[k].sx, sy = gp[k].sy, cs = gp[k].cs, ax = gp[k].ax, ay = gp[k].ay;
+        const f32x2 den = __builtin_elementwise_fma(-f.ndx, sy, -(f.dy * sx));
+        const f32x2 tn = __builtin_elementwise_fma(f.uy, sx, __builtin_elementwise_fma(f.nux, sy, cs));
+        const f32x2 un = __builtin_elementwise_fma(ax, f.dy, __builtin_elementwise_fma(ay, f.ndx, f.nku));
+        const f32x2 w = un - den;
+        const f32x2 rq = __builtin_elementwise_fma(-un, w, eq);
+        const f32x2 rp = __builtin_elementwise_fma(tn, den, ep);
+        acc = __builtin_amdgcn_alignbit(acc, __float_as_uint(rq.x) | __float_as_uint(rp.x), 31);
+        acc = __builtin_amdgcn_alignbit(acc, __float_as_uint(rq.y) | __float_as_uint(rp.y), 31);
+    }
+    return ~acc | force;
+}
+
 RT_DEV uint32_t filter_word(int n_circ, K_CirclePair c32, K_SegPair segp, const SegBounds &E, int lo, int hi,
                             const FilterRay &f, uint32_t force)
 {
@@ -285,6 +305,9 @@ struct CoopLds {
 // wave's in-order LDS execution).  The outcome is the minimum over all candidates of (key, pid): the
 // order of evaluation does not matter.  The ring never overflows: fewer than 64 entries are queued when
 // a word (<= 64 entries) is appended, and a round puts back at most what it took.
+// SEGW: the scene has words made of segments only, which then take their own straight-line filter (a kernel
+// compiled without it is ~1 % faster on scenes that have none).
+template <bool SEGW = true>
 RT_DEV Hit nearest_hit(SceneK S, double ox, double oy, double dx, double dy, bool active, CoopLds &L, Prof &prof)
 {
     S = fresh(S);
@@ -308,8 +331,10 @@ RT_DEV Hit nearest_hit(SceneK S, double ox, double oy, double dx, double dy, boo
         const int hi = (lo + 32 < P) ? lo + 32 : P;
         // bits below the word's last slot are shifted-in zeros; `force` may set them, so mask to the valid slots
         const uint32_t valid = 0xFFFFFFFFu << (32 - (hi - lo));
-        uint32_t mw = (hi <= n_circ && hi - lo == 32) ? filter_circle_word(c32 + (lo >> 1), fr, force)
-                                                      : filter_word(n_circ, c32, segp, E, lo, hi, fr, force) & valid;
+        uint32_t mw;
+        if (hi - lo == 32 && hi <= n_circ) mw = filter_circle_word(c32 + (lo >> 1), fr, force);
+        else if (SEGW && hi - lo == 32 && lo >= n_circ) mw = filter_segment_word(segp + ((lo - n_circ) >> 1), E, fr, force);
+        else mw = filter_word(n_circ, c32, segp, E, lo, hi, fr, force) & valid;
         if (!active) mw = 0u;
         RT_STAMP(prof, 1);
 #ifdef RT_PROF

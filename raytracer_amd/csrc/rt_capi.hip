@@ -656,10 +656,15 @@ int32_t launch_render2d(rt_ctx *ctx, const rt2d_scene *scene, const rt2d_render_
     }
     // persistent waves: as many workgroups as can be resident at once, never more waves than units
     const int waves_per_block = rtk::BLOCK / 64;
-    static int per_cu = 0; // resident workgroups per CU, as the runtime computes it from the kernel's registers and LDS
+    // the kernel is compiled twice: with and without the filter for words made of segments only
+    const int first_seg_word = (A.S.n_circ + 31) & ~31;
+    const bool segw = first_seg_word + 32 <= A.S.n_circ + A.S.n_seg;
+    void (*const kernel)(const rtk::Render2dArgs) = segw ? rtk::render2d_kernel<true> : rtk::render2d_kernel<false>;
+    static int per_cu_of[2] = { 0, 0 }; // resident workgroups per CU, as the runtime computes it from the kernel's registers and LDS
+    int &per_cu = per_cu_of[segw];
     if (per_cu == 0) {
         int nb = 0;
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, rtk::render2d_kernel, rtk::BLOCK, 0));
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, rtk::BLOCK, 0));
         per_cu = std::max(nb, 1);
         if (getenv("RT_AMD_VERBOSE")) fprintf(stderr, "[rt_amd] render2d: %d CUs x %d resident workgroups\n", ctx->n_cu, per_cu);
     }
@@ -670,7 +675,7 @@ int32_t launch_render2d(rt_ctx *ctx, const rt2d_scene *scene, const rt2d_render_
     if (int32_t rc = fold_events(ctx, 256)) return rc;
     if (int32_t rc = event_pair(ctx, &ev)) return rc;
     HIP_TRY(hipEventRecord(ev.first, ctx->stream));
-    hipLaunchKernelGGL(rtk::render2d_kernel, dim3((unsigned)blocks), dim3(rtk::BLOCK), 0, ctx->stream, A);
+    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(rtk::BLOCK), 0, ctx->stream, A);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(ev.second, ctx->stream));
     if (list_mode == 1) { // compute_pixel's `spectrum / spp`; mode 2 leaves the sums to the caller
