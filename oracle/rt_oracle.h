@@ -13,6 +13,9 @@
  * published Philox4x32-10 known-answer vectors and the CIE table.  The glam /
  * palette formulas it relies on (normalize = v * (1/len), reflect, refract,
  * XYZ->sRGB matrix) are restated from those crates' published definitions.
+ * The only outputs of the reference that exist - its gallery images - anchor
+ * the rendered worlds statistically (tests/test_gallery_oracle.py), not bit
+ * for bit.
  *
  * Arithmetic contract: f64 geometry, f32 radiance, no FMA contraction
  * (-ffp-contract=off), IEEE division and sqrt.  The reference draws randomness
