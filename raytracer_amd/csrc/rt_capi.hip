@@ -880,7 +880,8 @@ int32_t rt2d_render(rt_ctx *ctx, const rt2d_scene *scene, const rt2d_render_para
             for (int64_t i = 0; i < npx * RT_NBINS; ++i) out_spectrum[i] = out_spectrum[i] / spp;
         }
     }
-    (void)hipStreamSynchronize(ctx->stream);
+    e = hipStreamSynchronize(ctx->stream); // the host-pointer entry returns with its work done (and its faults reported)
+    if (!rc && e != hipSuccess) rc = fail(RT_E_HIP, "synchronize: %s", hipGetErrorString(e));
     return rc;
 }
 
@@ -961,7 +962,7 @@ int32_t rt2d_denoise(rt_ctx *ctx, const rt2d_scene *scene, const rt2d_render_par
     if (rc == RT_OK) rc = rt2d_denoise_device(ctx, scene, p, top, mask_size, oversampling_factor, d, d + 6 * n, d + 3 * n, out_recomputed);
     step(hipMemcpyAsync(merged_rgb, d, sizeof(float) * n * 3, hipMemcpyDeviceToHost, ctx->stream), "download");
     step(hipMemcpyAsync(merged_weight, d + 6 * n, sizeof(float) * n, hipMemcpyDeviceToHost, ctx->stream), "download");
-    (void)hipStreamSynchronize(ctx->stream);
+    step(hipStreamSynchronize(ctx->stream), "synchronize"); // a kernel fault surfaces here: the planes are then not valid
     (void)hipFree(d);
     return rc;
 }
@@ -1207,7 +1208,7 @@ int32_t rt2d_forward_render(rt_ctx *ctx, const rt2d_scene *scene, const rt2d_for
     if (rc == RT_OK) rc = rt2d_forward_accumulate(ctx, scene, p, d, d + 3 * n, out_lines);
     step(hipMemcpyAsync(out_rgb, d, sizeof(float) * n * 3, hipMemcpyDeviceToHost, ctx->stream), "download");
     step(hipMemcpyAsync(out_weight, d + 3 * n, sizeof(float) * n, hipMemcpyDeviceToHost, ctx->stream), "download");
-    (void)hipStreamSynchronize(ctx->stream);
+    step(hipStreamSynchronize(ctx->stream), "synchronize");
     (void)hipFree(d);
     return rc;
 }

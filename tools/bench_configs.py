@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
 """Timings of the BASELINE.json configs other than the headline one (bench.py covers configs[1]):
+cfg 2' the 2d stress-test scene at 3840x2160 (the north-star target's size; bench.py runs it at 1920x1080)
 cfg 3  2d dispersion / absorption scenes at 3840x2160, many wavelengths
 cfg 4  3d standalone scene at 1920x1080, spp 512, linear scan and BVH
 One JSON line per run (rays and kernel time come from the library's device counter and HIP events)."""
@@ -59,6 +60,7 @@ def main():
     run2d("cornell_box", 3840 // q, 2160 // q, 16, 16, 4 // min(q, 4) or 1)
     run2d("cornell_box_absorption", 3840 // q, 2160 // q, 16, 16, 4 // min(q, 4) or 1)
     run2d("sample_world", 1920 // q, 1080 // q, 64, 2, 1)
+    run2d("complex_world", 3840 // q, 2160 // q, 64, 2, 1)
     run3d(False, 1920 // q, 1080 // q, 512 // q)
     run3d(True, 1920 // q, 1080 // q, 512 // q)
 
