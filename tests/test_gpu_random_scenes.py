@@ -111,7 +111,10 @@ def compare2d(got, want):
 
 
 @pytest.mark.parametrize("n_circ,n_seg", [(1, 0), (0, 1), (31, 1), (33, 0), (200, 57), (255, 2), (256, 0), (1, 256),
-                                          (300, 300), (701, 5)])
+                                          (300, 300), (701, 5),
+                                          # word boundaries of the filters: all-circle and all-segment words of 32 slots take
+                                          # straight-line copies; 63 circles put the slot that pads an odd count inside one
+                                          (32, 0), (0, 32), (32, 32), (0, 64), (63, 32), (64, 33), (96, 31), (31, 97)])
 def test_random_world_fed_batch(n_circ, n_seg, gpu_ctx, oracle):
     rng = np.random.default_rng(1000 * n_circ + n_seg)
     world = random_world2d(rng, n_circ, n_seg, degenerate=(n_circ + n_seg) > 60)
