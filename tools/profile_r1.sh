@@ -6,7 +6,7 @@ TAG=${1:-r01}; shift || true
 OUT="$PWD/gpurun_out/prof_$TAG"
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-BENCH="python3 $PWD/bench.py --steps 3 --warmup 1 --cpu-spp 0 $*"
+BENCH="python3 $PWD/bench.py --steps 10 --warmup 2 --cpu-spp 0 $*"
 run() { # name, rocprof args...
   local name=$1; shift
   echo "== $name"
