@@ -66,6 +66,21 @@ def measured_traffic(workload_is_default):
     return None
 
 
+def measured_valu_busy(workload_is_default):
+    """Fraction of the SIMDs' cycles in which a vector instruction was executing, from the same committed PMC pass:
+    SQ_ACTIVE_INST_VALU x 4 over GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs.  Only valid for the default workload."""
+    if not workload_is_default:
+        return None
+    import glob
+    for f in reversed(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_*.json")))):
+        try:
+            d = json.load(open(f))["per_dispatch"]
+            return d["SQ_ACTIVE_INST_VALU"] * 4.0 / (d["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0)
+        except Exception:
+            continue
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -77,7 +92,7 @@ def main():
     ap.add_argument("--spp", type=int, default=64, help="samples per pixel per step")
     ap.add_argument("--lambda-samples", type=int, default=2)
     ap.add_argument("--depth", type=int, default=10)
-    ap.add_argument("--cpu-spp", type=int, default=4, help="spp of the bounded CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-spp", type=int, default=40, help="spp of the bounded CPU-baseline sample (0 = skip)")
     ap.add_argument("--merge", choices=("xyz", "spectral"), default="xyz",
                     help="N > 1: what the ranks all-reduce - their XYZ projections (12 B/pixel, default) or the spectral "
                          "buffers themselves (380 B/pixel); the image is the same up to f32 rounding order")
@@ -206,6 +221,8 @@ def main():
                          "frac": achieved / F64_VECTOR_PEAK_TFLOPS,
                          "traffic": measured_traffic((args.scene, W, H, args.spp, args.lambda_samples, args.depth)
                                                      == ("complex_world", 1920, 1080, 64, 2, 10)),
+                         "valu_busy": measured_valu_busy((args.scene, W, H, args.spp, args.lambda_samples, args.depth)
+                                                         == ("complex_world", 1920, 1080, 64, 2, 10)),
                          "kernel": "render2d_kernel", "kernel_ms": kernel_ms,
                          "flop_model": f"algorithmic: rays x (15 x {P} + 60) FLOP, the reference's f64 work per ray, over "
                                        "the measured launch time, against the f64 vector FMA peak; the kernel's own "
