@@ -67,3 +67,21 @@ def test_rt3d_standalone_writes_the_image_of_render(use_bvh, gpu_ctx, tmp_path):
     want = gpu_ctx.tonemap_reinhard(img, 1.0, 254).reshape(48, 64, 4)
     assert png[..., :3].any()
     assert close_bytes(png, want)
+
+
+@pytest.mark.parametrize("device_loop", [0, 1])
+def test_rt2d_reverse_progressive_loops_with_adaptive_passes(device_loop, tmp_path):
+    """endless_render (host merge as the reference does it) and the device-resident loop, two loops with the
+    re-sampling pass: the programs finish and their images show the same scene (the two merges differ by design:
+    encoded colours against linear sums, so the comparison is the rank order of block luminance)."""
+    from scipy.stats import spearmanr
+    run("rt2d_reverse", 1, 32, "cornell_box_absorption", 160, str(tmp_path / "loop_"), 2, 1, device_loop)
+    png = np.asarray(Image.open(tmp_path / "loop_0000.png")).astype(np.float64)
+    run("rt2d_reverse", 1, 64, "cornell_box_absorption", 160, str(tmp_path / "one_"))
+    one = np.asarray(Image.open(tmp_path / "one_0000.png")).astype(np.float64)
+    assert png.shape == one.shape == (120, 160, 4)
+    a = png[..., :3].reshape(15, 8, 20, 8, 3).mean(axis=(1, 3, 4))
+    b = one[..., :3].reshape(15, 8, 20, 8, 3).mean(axis=(1, 3, 4))
+    lit = b > 2.0
+    assert lit.sum() > 50
+    assert spearmanr(a[lit], b[lit])[0] > 0.95
