@@ -38,7 +38,11 @@ def main():
         print(json.dumps({"config": f"2d {name} {W}x{H} spp {spp * passes} lambda_samples {ls} depth 10", "primitives": P,
                           "kernel_ms": st["kernel_ms"], "rays": st["rays"], "samples": st["samples"],
                           "Mrays_per_s": st["rays"] / st["kernel_ms"] / 1e3, "Msamples_per_s": st["samples"] / st["kernel_ms"] / 1e3,
-                          "algorithmic_TFLOPs": st["rays"] * (15.0 * P + 60.0) / st["kernel_ms"] / 1e9}), flush=True)
+                          "algorithmic_TFLOPs": st["rays"] * (15.0 * P + 60.0) / st["kernel_ms"] / 1e9,
+                          # both roofline fractions: algorithmic FLOP against the 78.6 TFLOP/s f64 vector peak, and the
+                          # read-modify-write of the spectral buffer (2 x 380 B per pixel and launch) against 8 TB/s
+                          "frac_f64_vector_peak": st["rays"] * (15.0 * P + 60.0) / st["kernel_ms"] / 1e9 / 78.6,
+                          "frac_hbm_peak": passes * 2.0 * W * H * rt.NBINS * 4 / (st["kernel_ms"] * 1e-3) / 8e12}), flush=True)
         scene.close()
 
     def run3d(use_bvh, W, H, spp):
@@ -54,7 +58,11 @@ def main():
         print(json.dumps({"config": f"3d standalone scene (218 spheres) {W}x{H} spp {spp} bounce 10, {'BVH' if use_bvh else 'linear scan'}",
                           "kernel_ms": st["kernel_ms"], "rays": st["rays"], "samples": st["samples"],
                           "Mrays_per_s": st["rays"] / st["kernel_ms"] / 1e3, "Msamples_per_s": st["samples"] / st["kernel_ms"] / 1e3,
-                          "algorithmic_TFLOPs_linear_model": st["rays"] * (23.0 * 218 + 60.0) / st["kernel_ms"] / 1e9}), flush=True)
+                          "algorithmic_TFLOPs_linear_model": st["rays"] * (23.0 * 218 + 60.0) / st["kernel_ms"] / 1e9,
+                          # the linear scan's work is what the reference does; the BVH kernel returns the same hits with
+                          # less of it, so its fraction says how far it is ahead of a perfect linear scan
+                          "frac_f64_vector_peak_linear_model": st["rays"] * (23.0 * 218 + 60.0) / st["kernel_ms"] / 1e9 / 78.6,
+                          "frac_hbm_peak": 2.0 * W * H * 3 * 4 / (st["kernel_ms"] * 1e-3) / 8e12}), flush=True)
         scene.close()
 
     run2d("cornell_box", 3840 // q, 2160 // q, 16, 16, 4 // min(q, 4) or 1)
