@@ -124,6 +124,37 @@ def test_random_world_fed_batch(n_circ, n_seg, gpu_ctx, oracle):
     scene.close()
 
 
+@pytest.mark.parametrize("scale,offset", [(1e-3, (0.0, 0.0)), (1.0, (1e7, -3e6)), (1e4, (0.0, 0.0)), (1e-2, (-5e4, 5e4)),
+                                          (1.0, (3e11, 3e11))])
+def test_world_at_other_scales_and_far_from_the_origin(scale, offset, gpu_ctx, oracle):
+    """The f32 filters work in a frame centred on the scene, whatever its place and size in world coordinates; at
+    3e11 from the origin an f64 coordinate resolves 6e-5, so circles and segments are visibly quantised - on both sides alike."""
+    rng = np.random.default_rng(4242)
+    base = random_world2d(rng, 70, 45, degenerate=True)
+    ox, oy, dx, dy, li = rays2d(base, 30_000, rng)
+    a = {k: np.array(v, copy=True) for k, v in base._a.items()}
+    for k in ("circle_cx", "seg_ax", "seg_bx"):
+        a[k] = a[k] * scale + offset[0]
+    for k in ("circle_cy", "seg_ay", "seg_by"):
+        a[k] = a[k] * scale + offset[1]
+    a["circle_r"] = a["circle_r"] * scale
+    # Segment::new on the moved end points (rt_common.rs:233-240)
+    sx, sy = a["seg_bx"] - a["seg_ax"], a["seg_by"] - a["seg_ay"]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        rl = 1.0 / np.sqrt((-sy) * (-sy) + sx * sx)
+        nx, ny = (-sy) * rl, sx * rl
+    bad = ~np.isfinite(nx) | ~np.isfinite(ny)
+    nx[bad], ny[bad] = 1.0, 0.0
+    a["seg_nx"], a["seg_ny"] = nx, ny
+    world = rt.ArrayWorld2D(a)
+    scene = rt.Scene2D(gpu_ctx, world)
+    rays = (ox * scale + offset[0], oy * scale + offset[1], dx, dy, li)
+    got, want = scene.trace_batch(*rays, depth=10, seed=9), oracle.trace_batch2d(world, *rays, depth=10, seed=9)
+    compare2d(got, want)
+    assert (got[1] >= 0).mean() > 0.5     # most rays do hit something: the moved rays meet the moved scene
+    scene.close()
+
+
 @pytest.mark.parametrize("n_circ,n_seg,w,h", [(40, 25, 24, 16), (7, 300, 19, 9)])
 def test_random_world_render(n_circ, n_seg, w, h, gpu_ctx, oracle):
     rng = np.random.default_rng(77 + n_circ)
