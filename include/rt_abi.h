@@ -156,7 +156,8 @@ int32_t rt2d_scene_destroy(rt2d_scene *scene);
 /* ---- 2d: whole image ------------------------------------------------------
  * ReverseRenderer::global_render (librt2d_reverse.rs:282-302) for one pass of
  * `spp` samples: out_rgb[W*y+x][3] = Spectrum::to_dvec3 of the pixel's mean
- * spectrum (spectrum.rs:242-278), out_weight[W*y+x] = spp (librt2d_reverse.rs:
+ * spectrum (spectrum.rs:242-278: sRGB-encoded, each channel in [0, 1] as
+ * palette's clamped into_color leaves it), out_weight[W*y+x] = spp (librt2d_reverse.rs:
  * 291-294, img.rs:20-24,93-99); out_spectrum (nullable) [W*y+x][95] = the value
  * compute_pixel returns.  Host pointers.                                      */
 int32_t rt2d_render(rt_ctx *ctx, const rt2d_scene *scene, const rt2d_render_params *params,

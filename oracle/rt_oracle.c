@@ -974,8 +974,18 @@ int rto2d_forward_render(const rto2d_scene *sc, int32_t width, int32_t height, i
     return 0;
 }
 
+/* One channel of palette 0.7.7's `Xyz<D65, f32>::into_color() -> Srgb<f32>` after the matrix (spectrum.rs:258-259):
+ * the sRGB transfer function, then - `into_color` is the CLAMPED conversion (`from_color_unclamped(..).clamp()`),
+ * unlike `into_color_unclamped` - the channel limited to [0, 1].  Every image in the reference's gallery has 127 =
+ * (1 / (1 + 1) * 255) as u8 as its largest byte, which is what a channel capped at 1 gives under Reinhard(1). */
+static inline float srgb_channel(float c)
+{
+    const float e = (c <= 0.0031308f) ? 12.92f * c : 1.055f * powf(c, 1.0f / 2.4f) - 0.055f;
+    return (e < 0.0f) ? 0.0f : (e > 1.0f) ? 1.0f : e;
+}
+
 /* Spectrum::to_xyz + to_dvec3, 2d/src/spectrum.rs:242-278; palette Xyz<D65> -> Srgb:
- * linear = M * XYZ (sRGB/D65 matrix), then the sRGB transfer function, no clamping. */
+ * linear = M * XYZ (sRGB/D65 matrix), then the sRGB transfer function and the clamp to [0, 1]. */
 void rto_resolve_pixel(const float spectrum[RTO_NBINS], float rgb[3])
 {
     float x = 0.0f, y = 0.0f, z = 0.0f;
@@ -988,10 +998,7 @@ void rto_resolve_pixel(const float spectrum[RTO_NBINS], float rgb[3])
     lin[0] = 3.2404542f * x + -1.5371385f * y + -0.4985314f * z;
     lin[1] = -0.9692660f * x + 1.8760108f * y + 0.0415560f * z;
     lin[2] = 0.0556434f * x + -0.2040259f * y + 1.0572252f * z;
-    for (int k = 0; k < 3; ++k) {
-        float c = lin[k];
-        rgb[k] = (c <= 0.0031308f) ? 12.92f * c : 1.055f * powf(c, 1.0f / 2.4f) - 0.055f;
-    }
+    for (int k = 0; k < 3; ++k) rgb[k] = srgb_channel(lin[k]);
 }
 
 /* The resolve in two steps around a sum over processes (to_xyz is linear): xyz = sum_b spectrum_sum[b] * cmf[b],
@@ -1014,10 +1021,7 @@ void rto_encode_xyz(const float xyz[3], float total_spp, float rgb[3])
     lin[0] = 3.2404542f * x + -1.5371385f * y + -0.4985314f * z;
     lin[1] = -0.9692660f * x + 1.8760108f * y + 0.0415560f * z;
     lin[2] = 0.0556434f * x + -0.2040259f * y + 1.0572252f * z;
-    for (int k = 0; k < 3; ++k) {
-        float c = lin[k];
-        rgb[k] = (c <= 0.0031308f) ? 12.92f * c : 1.055f * powf(c, 1.0f / 2.4f) - 0.055f;
-    }
+    for (int k = 0; k < 3; ++k) rgb[k] = srgb_channel(lin[k]);
 }
 
 /* RawImage::convert_to_image(Reinhard), 2d/src/img.rs:187-218 (alpha 255) and

@@ -15,7 +15,8 @@
  * XYZ->sRGB matrix) are restated from those crates' published definitions.
  * The only outputs of the reference that exist - its gallery images - anchor
  * the rendered worlds statistically (tests/test_gallery_oracle.py), not bit
- * for bit.
+ * for bit; they also show that palette's into_color() clamps to [0, 1]
+ * (largest byte 127 in every image).
  *
  * Arithmetic contract: f64 geometry, f32 radiance, no FMA contraction
  * (-ffp-contract=off), IEEE division and sqrt.  The reference draws randomness

@@ -1,8 +1,11 @@
 """Statistics that compare a render with one of the reference's gallery images (tests/golden/gallery_lowres.npz, made
 by tests/golden/make_gallery.py).  The gallery images went through the reference's GUI: unseeded generator, unknown
-loop count, unknown tone-mapping parameter.  What survives that is ORDER and HUE at low resolution: on 30x40 block
-means, the rank correlation of luminance over the blocks the reference shows lit, and - where the reference is
-colourful - which of R, G, B dominates the block."""
+loop count.  Two comparisons on 30x40 block means:
+ * compare(): ORDER and HUE, which survive any monotone tone map - the rank correlation of luminance over the blocks
+   the reference shows lit, and, where the reference is colourful, which of R, G, B dominates the block;
+ * compare_bytes(): the tone-mapped bytes themselves.  Every gallery image has 127 as its largest byte, i.e. channel
+   values capped at 1 (palette's clamped `into_color`) under Reinhard with parameter 1, so a converged render encoded
+   the same way can be laid over the reference's image directly."""
 import os
 
 import numpy as np
@@ -35,3 +38,12 @@ def compare(linear_rgb, ref_blocks):
     black = lum_r < 0.004
     leak = float(np.abs(lum_o[black]).max() / lum_o.max()) if black.any() else 0.0
     return rho, int(colourful.sum()), agree, leak
+
+
+def compare_bytes(rgba8, ref_blocks):
+    """rgba8: [600][800][4] bytes of a render after Reinhard(1).  Returns (mean |difference| of the block means in
+    units of full scale, their Pearson correlation, the largest colour byte)."""
+    img = np.asarray(rgba8)[..., :3]
+    ours = block_means(img.astype(np.float64) / 255.0)
+    ref = ref_blocks.astype(np.float64)
+    return float(np.abs(ours - ref).mean()), float(np.corrcoef(ours.ravel(), ref.ravel())[0, 1]), int(img.max())

@@ -231,13 +231,21 @@ def test_resolve_matches_independent_numpy(oracle):
     cmf = oracle.cmf()
     m = np.array([[3.2404542, -1.5371385, -0.4985314], [-0.9692660, 1.8760108, 0.0415560], [0.0556434, -0.2040259, 1.0572252]],
                  np.float32)
-    for spec in (np.ones(95, np.float32), rng.random(95).astype(np.float32) * 0.02, np.zeros(95, np.float32)):
+    narrow = np.zeros(95, np.float32)
+    narrow[10] = 0.5                       # a 410 nm line: green comes out negative before the clamp
+    for spec in (np.ones(95, np.float32), rng.random(95).astype(np.float32) * 0.02, np.zeros(95, np.float32), narrow):
         xyz = np.zeros(3, np.float32)
         for i in range(95):
             xyz = xyz + spec[i] * cmf[i]
         lin = np.array([np.float32(m[r, 0] * xyz[0]) + np.float32(m[r, 1] * xyz[1]) + np.float32(m[r, 2] * xyz[2]) for r in range(3)])
-        want = np.where(lin <= 0.0031308, 12.92 * lin, 1.055 * np.power(lin.astype(np.float64), 1 / 2.4) - 0.055)
-        assert np.allclose(oracle.resolve_pixel(spec), want, rtol=2e-6, atol=1e-7)
+        with np.errstate(invalid="ignore"):
+            want = np.where(lin <= 0.0031308, 12.92 * lin, 1.055 * np.power(lin.astype(np.float64), 1 / 2.4) - 0.055)
+        want = np.clip(want, 0.0, 1.0)     # palette's `into_color` is the clamped conversion
+        got = oracle.resolve_pixel(spec)
+        assert np.allclose(got, want, rtol=2e-6, atol=1e-7)
+        assert got.min() >= 0.0 and got.max() <= 1.0
+    assert oracle.resolve_pixel(np.ones(95, np.float32)).tolist() == [1.0, 1.0, 1.0]   # far above 1 before the clamp
+    assert oracle.resolve_pixel(narrow)[1] == 0.0
 
 
 def test_reinhard_cast_saturates(oracle):
