@@ -307,7 +307,8 @@ struct CoopLds {
 // a word (<= 64 entries) is appended, and a round puts back at most what it took.
 // SEGW: the scene has words made of segments only, which then take their own straight-line filter (a kernel
 // compiled without it is ~1 % faster on scenes that have none).
-template <bool SEGW = true>
+// SMALL: the scene has at most 32 slots (and at least one).
+template <bool SEGW = true, bool SMALL = false>
 RT_DEV Hit nearest_hit(SceneK S, double ox, double oy, double dx, double dy, bool active, CoopLds &L, Prof &prof)
 {
     S = fresh(S);
@@ -324,6 +325,60 @@ RT_DEV Hit nearest_hit(SceneK S, double ox, double oy, double dx, double dy, boo
     bool in_range;
     const FilterRay fr = filter_ray(S, ox, oy, dx, dy, in_range);
     const uint32_t force = in_range ? 0u : 0xFFFFFFFFu;
+    if (SMALL) {
+        // The whole scene is one word: every lane's candidates sit in its own mask, a shared queue has nothing to
+        // balance (the wave would walk max-over-lanes entries either way) and its LDS traffic and permutes are pure
+        // cost.  Each lane walks its own bits and keeps the minimum of (key, pid) in registers.
+        uint32_t mw = filter_word(n_circ, c32, segp, E, 0, P, fr, force) & (0xFFFFFFFFu << (32 - P));
+        if (!active) mw = 0u;
+        int64_t bk = 0x7fffffffffffffffLL;
+        uint64_t bps = ~0ull;
+        auto keep = [&](bool got, double t, int pid, int s) {
+            const int64_t key = total_key(t);
+            const uint64_t ps = ((uint64_t)(uint32_t)pid << 32) | (uint64_t)(uint32_t)s;
+            if (got && (key < bk || (key == bk && ps < bps))) {
+                bk = key;
+                bps = ps;
+            }
+        };
+        // circles first, then segments: a step of the wave then runs one kind of test, not both
+        uint32_t mc = (n_circ >= 32) ? mw : (mw & ~(0xFFFFFFFFu >> n_circ));
+        uint32_t ms = mw & ~mc;
+        while (__any(mc != 0u)) {
+            const int s = __clz((int)mc) & 31;
+            const bool on = mc != 0u;
+            mc &= ~(0x80000000u >> s);
+            bool got = false;
+            double t = 0.0;
+            int pid = 0;
+            if (on) {
+                const CircleX c = cex[s];
+                got = circle_t(ox, oy, dx, dy, c.cx, c.cy, c.r2, t);
+                pid = c.pid;
+            }
+            keep(got, t, pid, s);
+        }
+        while (__any(ms != 0u)) {
+            const int s = __clz((int)ms) & 31;
+            const bool on = ms != 0u;
+            ms &= ~(0x80000000u >> s);
+            bool got = false;
+            double t = 0.0;
+            int pid = 0;
+            if (on) {
+                const SegX g = sex[s - n_circ];
+                got = segment_t(ox, oy, dx, dy, g.ax, g.ay, g.sx, g.sy, t);
+                pid = g.pid;
+            }
+            keep(got, t, pid, s);
+        }
+        Hit best;
+        const bool found = bk != 0x7fffffffffffffffLL;
+        best.t = found ? __longlong_as_double(bk ^ (int64_t)((uint64_t)(bk >> 63) >> 1)) : 0.0;
+        best.slot = found ? (int32_t)(uint32_t)bps : -1;
+        best.pid = found ? (int32_t)(bps >> 32) : 0x7fffffff;
+        return best;
+    }
     L.key[lane] = 0x7fffffffffffffffLL;
     L.pidslot[lane] = ~0ull;
     int head = 0, count = 0; // wave-uniform

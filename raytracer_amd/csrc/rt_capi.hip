@@ -659,9 +659,13 @@ int32_t launch_render2d(rt_ctx *ctx, const rt2d_scene *scene, const rt2d_render_
     // the kernel is compiled twice: with and without the filter for words made of segments only
     const int first_seg_word = (A.S.n_circ + 31) & ~31;
     const bool segw = first_seg_word + 32 <= A.S.n_circ + A.S.n_seg;
-    void (*const kernel)(const rtk::Render2dArgs) = segw ? rtk::render2d_kernel<true> : rtk::render2d_kernel<false>;
-    static int per_cu_of[2] = { 0, 0 }; // resident workgroups per CU, as the runtime computes it from the kernel's registers and LDS
-    int &per_cu = per_cu_of[segw];
+    // ... and a third time for scenes of one word (at most 32 slots), which need no shared candidate queue
+    const int n_slots = A.S.n_circ + A.S.n_seg;
+    const bool small = n_slots >= 1 && n_slots <= 32;
+    void (*const kernel)(const rtk::Render2dArgs) = small ? rtk::render2d_kernel<false, true>
+                                                   : segw ? rtk::render2d_kernel<true> : rtk::render2d_kernel<false>;
+    static int per_cu_of[3] = { 0, 0, 0 }; // resident workgroups per CU, as the runtime computes it from the kernel's registers and LDS
+    int &per_cu = per_cu_of[small ? 2 : (int)segw];
     if (per_cu == 0) {
         int nb = 0;
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, rtk::BLOCK, 0));
