@@ -68,7 +68,9 @@ def measured_traffic(workload_is_default):
 
 def measured_valu_busy(workload_is_default):
     """Fraction of the SIMDs' cycles in which a vector instruction was executing, from the same committed PMC pass:
-    SQ_ACTIVE_INST_VALU x 4 over GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs.  Only valid for the default workload."""
+    SQ_ACTIVE_INST_VALU x 4 over GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs.  The counter sums per-wave execution cycles,
+    which overlap in the pipeline, so it can overstate (it reads 1.04 on an 11-primitive scene): an indicator that the
+    vector pipe is saturated, not a precise fraction.  Only valid for the default workload."""
     if not workload_is_default:
         return None
     import glob
