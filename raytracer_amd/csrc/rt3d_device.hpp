@@ -263,7 +263,14 @@ RT_DEV Hit nearest_hit(const SceneDev &S, double ox, double oy, double oz, doubl
         scan_range<true>(S, 0, S.n, ox, oy, oz, dx, dy, dz, active, best, best_key);
         return best;
     }
-    scan_range<false>(S, 0, S.n_always, ox, oy, oz, dx, dy, dz, active, best, best_key);
+    // the spheres kept out of the tree are one or two (the ground): the exact test on every lane costs less than the
+    // filter pass over eight mostly empty words and its mask bookkeeping (standalone scene: 31.2 -> 33.5 Grays/s)
+    if (S.n_always <= 4) {
+        if (active)
+            for (int s = 0; s < S.n_always; ++s) consider(S, s, ox, oy, oz, dx, dy, dz, best, best_key);
+    } else {
+        scan_range<false>(S, 0, S.n_always, ox, oy, oz, dx, dy, dz, active, best, best_key);
+    }
     if (S.n_nodes == 0) return best;
     const float oxf = (float)ox, oyf = (float)oy, ozf = (float)oz;
     const float pad = (__builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(oxf), __builtin_fabsf(oyf)), __builtin_fabsf(ozf)) + (float)S.box_scale) * 0x1.0p-21f;
