@@ -50,9 +50,10 @@ int main(int argc, char **argv)
             const double t = (double)idx / (double)(frames > 1 ? frames : 60);
             const World world = worlds::by_name(world_name, camera, t, (uint64_t)idx, 1);
             auto progress = [](size_t n, const RawImage &) { printf("loop %zu\n", n); return true; };
-            const RawImage raw = loops == 0 ? renderer.global_render(world, params)
-                                 : device_loop ? renderer.endless_render_device(world, progress)
-                                               : renderer.endless_render(world, progress);
+            RawImage raw = loops == 0 ? renderer.global_render(world, params)
+                           : device_loop ? renderer.endless_render_device(world, progress)
+                                         : renderer.endless_render(world, progress);
+            annotate(raw, camera, DVec2(0.0, 0.0)); // 2d_reverse.rs:52
             std::vector<float> rgb((size_t)width * height * 3);
             for (size_t i = 0; i < raw.data.size(); ++i) {
                 rgb[3 * i] = raw.data[i].value.x; rgb[3 * i + 1] = raw.data[i].value.y; rgb[3 * i + 2] = raw.data[i].value.z;

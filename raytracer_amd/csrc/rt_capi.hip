@@ -81,6 +81,9 @@ struct rt_ctx {
     void *acc = nullptr;
     size_t acc_bytes = 0;
     int live_scenes = 0; // scenes created on this context and not yet destroyed
+    // resident workgroups per CU of the three render2d_kernel instantiations on this device, as the runtime computes
+    // them from the kernel's registers and LDS (0 = not asked yet)
+    int per_cu2d[3] = { 0, 0, 0 };
 };
 
 struct rt2d_scene {
@@ -412,7 +415,9 @@ int32_t rt2d_scene_create(rt_ctx *ctx, const rt2d_scene_desc *d, rt2d_scene **ou
         rt2d::SegX *sex = c.take<rt2d::SegX>(ns);
         rt2d::SegPair *segp = c.take<rt2d::SegPair>((size_t)nsp2 / 2);
         rt2d::MatDev *mats = c.take<rt2d::MatDev>(no);
-        float *spectra = c.take<float>((size_t)nsp * RT_NBINS);
+        // at least one (zero) row: shade() may load a hit's spectrum value before it has classified the material, and
+        // a scene of mirrors only has no spectra of its own
+        float *spectra = c.take<float>((size_t)std::max(nsp, 1) * RT_NBINS);
         if (host) {
             char *hb = host->data();
             auto H = [&](auto *p) { return reinterpret_cast<decltype(p)>(hb + (reinterpret_cast<char *>(p) - c.base)); };
@@ -664,8 +669,7 @@ int32_t launch_render2d(rt_ctx *ctx, const rt2d_scene *scene, const rt2d_render_
     const bool small = n_slots >= 1 && n_slots <= 32;
     void (*const kernel)(const rtk::Render2dArgs) = small ? rtk::render2d_kernel<false, true>
                                                    : segw ? rtk::render2d_kernel<true> : rtk::render2d_kernel<false>;
-    static int per_cu_of[3] = { 0, 0, 0 }; // resident workgroups per CU, as the runtime computes it from the kernel's registers and LDS
-    int &per_cu = per_cu_of[small ? 2 : (int)segw];
+    int &per_cu = ctx->per_cu2d[small ? 2 : (int)segw]; // per context: contexts live on different devices and threads
     if (per_cu == 0) {
         int nb = 0;
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, rtk::BLOCK, 0));

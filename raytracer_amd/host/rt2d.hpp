@@ -225,6 +225,22 @@ struct FlatScene {
         d.materials = materials.data(); d.spectra = spectra.data();
         return d;
     }
+
+    // Same geometry, materials and spectra, value for value (NaNs compare unequal: such a scene is uploaded again).
+    bool operator==(const FlatScene &o) const
+    {
+        if (!(ccx == o.ccx && ccy == o.ccy && cr == o.cr && sax == o.sax && say == o.say && sbx == o.sbx && sby == o.sby &&
+              snx == o.snx && sny == o.sny && cobj == o.cobj && cpid == o.cpid && sobj == o.sobj && spid == o.spid &&
+              spectra == o.spectra && materials.size() == o.materials.size()))
+            return false;
+        for (size_t i = 0; i < materials.size(); ++i) {
+            const rt2d_material &a = materials[i], &b = o.materials[i];
+            if (!(a.kind == b.kind && a.ior_kind == b.ior_kind && a.ior_a == b.ior_a && a.ior_b == b.ior_b && a.angle == b.angle &&
+                  a.d == b.d && a.spectrum == b.spectrum))
+                return false;
+        }
+        return true;
+    }
 };
 
 // Object list -> SoA in scan order (object order, then segment order inside a Strip).
@@ -296,6 +312,20 @@ struct RawImage {
         return true;
     }
 };
+
+// rt_common.rs:23-41: a red tick (value = Vec3::X, weight 1, Blending::Replace) 5 pixels long at every 100th
+// column of the top edge and every 100th row of the left edge, as far as camera.size reaches; ticks outside the
+// image are ignored as the reference ignores draw_pixel's Err.  `p` is unused there as well.
+inline void annotate(RawImage &raw_image, const Camera &camera, DVec2 /*p*/)
+{
+    PixelData pixel_data;
+    pixel_data.value = Vec3{ 1.0f, 0.0f, 0.0f };
+    pixel_data.weight = 1.0f;
+    for (int i = 0; i < (int)camera.size.x / 100; ++i)
+        for (int j = 0; j < 5; ++j) (void)raw_image.draw_pixel(i * 100, j, pixel_data, Blending::Replace);
+    for (int j = 0; j < (int)camera.size.y / 100; ++j)
+        for (int i = 0; i < 5; ++i) (void)raw_image.draw_pixel(i, j * 100, pixel_data, Blending::Replace);
+}
 
 // ---- librt2d_reverse.rs -----------------------------------------------------
 // librt2d_reverse.rs:55-60
@@ -386,16 +416,25 @@ public:
         return compute_pixels(p, { px }, { py })[0];
     }
 
-    // librt2d_reverse.rs:112-262.  `ray_index` names the ray's random stream.
-    float trace_ray(const World &world, const Ray2d &ray, size_t lambda_idx, double /*lambda*/, size_t depth)
+    // librt2d_reverse.rs:112-262.  The reference draws fresh random numbers in every call (diffuse bounces,
+    // rt_common.rs:376-391), so a caller that averages repeated calls converges; here every call takes the next
+    // random stream of this renderer.  trace_ray_at names the stream, for callers that want a call reproduced.
+    float trace_ray(const World &world, const Ray2d &ray, size_t lambda_idx, double lambda, size_t depth)
+    {
+        return trace_ray_at(world, ray, lambda_idx, lambda, depth, next_stream_++);
+    }
+    float trace_ray_at(const World &world, const Ray2d &ray, size_t lambda_idx, double /*lambda*/, size_t depth, uint64_t stream)
     {
         bind(world);
         const int32_t li = (int32_t)lambda_idx;
         float out = 0.0f;
         check(rt2d_trace_batch(ctx_, scene_, 1, &ray.origin.x, &ray.origin.y, &ray.dir.x, &ray.dir.y, &li, (int32_t)depth,
-                               render_params.seed, &out, nullptr, nullptr, nullptr));
+                               stream_seed(render_params.seed, stream), &out, nullptr, nullptr, nullptr));
         return out;
     }
+    // Philox key of stream k of a renderer seeded with `seed`: stream 0 is the seed itself, later ones are spread
+    // over the key space by a odd 64-bit multiplier (distinct k give distinct keys).
+    static uint64_t stream_seed(uint64_t seed, uint64_t k) { return seed + k * 0x9E3779B97F4A7C15ull; }
 
     // librt2d_reverse.rs:337-422, one pass: re-samples the noisiest pixels of `merged` (judged against `loop`) with the
     // samples [p.sample_offset, p.sample_offset + p.spp) and adds them.  Returns the number of recomputed pixels.
@@ -503,16 +542,19 @@ public:
         return out;
     }
 
-    // Upload `world` unless it is the one already resident (compared by address and object count).
+    // Upload `world` unless the scene already resident has the same CONTENT.  The reference borrows `&World` per call
+    // and reads it afresh every time (librt2d_reverse.rs:282-285); its shipped caller builds a new world per frame
+    // in a loop-local variable (bin/2d_reverse.rs:45-51), which lands at the same address with the same object count
+    // frame after frame, so neither says anything about what the world holds.  Flattening and comparing a few KB
+    // (76 KB for 200 objects) is noise beside a render.
     void bind(const World &world)
     {
-        if (scene_ && bound_ == &world && bound_objects_ == world.objects.size()) return;
+        FlatScene f = flatten(world);
+        if (scene_ && f == bound_) return;
         if (scene_) { rt2d_scene_destroy(scene_); scene_ = nullptr; }
-        const FlatScene f = flatten(world);
         const rt2d_scene_desc d = f.desc();
         check(rt2d_scene_create(ctx_, &d, &scene_));
-        bound_ = &world;
-        bound_objects_ = world.objects.size();
+        bound_ = std::move(f);
     }
 
 private:
@@ -530,8 +572,8 @@ private:
     }
     rt_ctx *ctx_ = nullptr;
     rt2d_scene *scene_ = nullptr;
-    const World *bound_ = nullptr;
-    size_t bound_objects_ = 0;
+    FlatScene bound_; // content of the scene resident on the GPU
+    uint64_t next_stream_ = 0; // random stream of the next trace_ray call
 };
 
 // ---- librt2d_forward.rs -----------------------------------------------------
@@ -604,15 +646,15 @@ public:
     }
 
 private:
+    // as ReverseRenderer::bind: the resident scene is kept only while the world's content is unchanged
     void bind(const World &world)
     {
-        if (scene_ && bound_ == &world && bound_objects_ == world.objects.size()) return;
+        FlatScene f = flatten(world);
+        if (scene_ && f == bound_) return;
         if (scene_) { rt2d_scene_destroy(scene_); scene_ = nullptr; }
-        const FlatScene f = flatten(world);
         const rt2d_scene_desc d = f.desc();
         check(rt2d_scene_create(ctx_, &d, &scene_));
-        bound_ = &world;
-        bound_objects_ = world.objects.size();
+        bound_ = std::move(f);
     }
     static void check(int32_t rc)
     {
@@ -621,8 +663,7 @@ private:
     ForwardRenderParams render_params_;
     rt_ctx *ctx_ = nullptr;
     rt2d_scene *scene_ = nullptr;
-    const World *bound_ = nullptr;
-    size_t bound_objects_ = 0;
+    FlatScene bound_; // content of the scene resident on the GPU
     int32_t next_ray_ = 0;
 };
 

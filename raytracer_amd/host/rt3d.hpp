@@ -78,12 +78,16 @@ public:
         return img;
     }
 
-    // rt.rs:216-236 (the object slice argument is the world's own list, as at every call site)
-    Color trace_ray(const Ray &ray, size_t bounce_limit)
+    // rt.rs:216-236 (the object slice argument is the world's own list, as at every call site).  The reference draws
+    // fresh random numbers for every call's bounces (rt.rs:41): each call here takes the next random stream of this
+    // world; trace_ray_at names the stream, for a call that has to be reproduced.
+    Color trace_ray(const Ray &ray, size_t bounce_limit) { return trace_ray_at(ray, bounce_limit, next_stream_++); }
+    Color trace_ray_at(const Ray &ray, size_t bounce_limit, uint64_t stream)
     {
         const double o[3] = { ray.origin.x, ray.origin.y, ray.origin.z }, d[3] = { ray.dir.x, ray.dir.y, ray.dir.z };
         float rgb[3];
-        check(rt3d_trace_batch(ctx_, scene_, 1, o, d, (int32_t)bounce_limit, params_.seed, rgb, nullptr, nullptr, nullptr));
+        check(rt3d_trace_batch(ctx_, scene_, 1, o, d, (int32_t)bounce_limit, params_.seed + stream * 0x9E3779B97F4A7C15ull, rgb,
+                               nullptr, nullptr, nullptr));
         return Color{ rgb[0], rgb[1], rgb[2] };
     }
 
@@ -98,6 +102,7 @@ private:
     RenderParams params_;
     rt_ctx *ctx_ = nullptr;
     rt3d_scene *scene_ = nullptr;
+    uint64_t next_stream_ = 0; // random stream of the next trace_ray call
 };
 
 // The scene of 3d/src/bin/standalone.rs:21-49: a 6x6x6 grid of spheres r = 0.8
