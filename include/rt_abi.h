@@ -309,6 +309,17 @@ int32_t rt2d_forward_accumulate(rt_ctx *ctx, const rt2d_scene *scene, const rt2d
                                 void *d_rgb, void *d_weight, int64_t *out_lines);
 int32_t rt2d_forward_render(rt_ctx *ctx, const rt2d_scene *scene, const rt2d_forward_params *params,
                             float *out_rgb, float *out_weight, int64_t *out_lines);
+/* rt2d_forward_accumulate for callers that cannot allocate device memory (code under HIP graph capture, tight
+ * serving loops, harnesses that forbid hipMalloc).  It has no counterpart in the reference.  Same inputs, same
+ * result on d_rgb / d_weight; what differs: its scratch (the buffer of last rays between the trace and the
+ * drawing kernel, the coverage plane, the line counter) is a fixed array inside the library's code object, 11 MB per
+ * GPU, instead of the context's grow-only workspace, and the call makes no hipMalloc / hipFree, creates no event
+ * and never synchronises.  Limits: width * height <= 2^20 pixels (RT_E_LIMIT beyond; the reference draws 800 x 600).
+ * d_lines (nullable) is DEVICE memory, one uint64: it receives the number of lines drawn, on the context's stream.
+ * All calls on one GPU share that GPU's array: calls that overlap in time on one GPU (two contexts or two streams)
+ * race; calls ordered on one stream do not.                                                                     */
+int32_t rt2d_forward_accumulate_static(rt_ctx *ctx, const rt2d_scene *scene, const rt2d_forward_params *params,
+                                       void *d_rgb, void *d_weight, void *d_lines);
 
 /* ---- 2d: fed ray batches --------------------------------------------------
  * ReverseRenderer::trace_ray (librt2d_reverse.rs:112-262) for n rays:

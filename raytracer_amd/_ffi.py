@@ -104,6 +104,8 @@ ABI = {
                                             C.POINTER(C.c_void_p)]),
     "rt2d_forward_accumulate": (C.c_int32, [C.c_void_p, C.c_void_p, C.POINTER(ForwardParams2D), C.c_void_p, C.c_void_p,
                                             C.POINTER(C.c_int64)]),
+    "rt2d_forward_accumulate_static": (C.c_int32, [C.c_void_p, C.c_void_p, C.POINTER(ForwardParams2D), C.c_void_p, C.c_void_p,
+                                                   C.c_void_p]),
     "rt2d_forward_render": (C.c_int32, [C.c_void_p, C.c_void_p, C.POINTER(ForwardParams2D), c_float_p, c_float_p,
                                         C.POINTER(C.c_int64)]),
     "rt2d_trace_batch": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int64, c_double_p, c_double_p, c_double_p, c_double_p,

@@ -421,6 +421,12 @@ class Scene2D:
                                                  C.byref(n) if count_lines else None))
         return n.value if count_lines else None
 
+    def forward_accumulate_static(self, p, d_rgb_ptr, d_weight_ptr, d_lines_ptr=None):
+        """forward_accumulate without any allocation (scratch inside the library, images up to 2^20 pixels);
+        d_lines_ptr: device uint64 that receives the number of lines drawn.  Never synchronises."""
+        check(_ffi.lib().rt2d_forward_accumulate_static(self.ctx._ctx, self._sc, C.byref(p), C.c_void_p(d_rgb_ptr),
+                                                        C.c_void_p(d_weight_ptr), C.c_void_p(d_lines_ptr) if d_lines_ptr else None))
+
     def progressive(self, p, denoiser=None):
         """Device-resident endless_render loop: see Progressive2D."""
         return Progressive2D(self, p, denoiser)

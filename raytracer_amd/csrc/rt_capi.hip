@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <utility>
@@ -19,9 +20,27 @@
 
 #include "rt_kernels.hpp"
 
+// Scratch of rt2d_forward_accumulate_static, the entry point that allocates nothing: the staging buffer of last rays
+// between the trace and the splat kernel, the (coverage, count) plane the splat kernel adds into, and the line
+// counter.  One copy per GPU, held from the moment the library's code object is loaded on it until the process ends.
+// Host code never uses this name as an address: rt_ctx_create asks the runtime where the array lives on the
+// context's device (hipGetSymbolAddress) and every later use goes through that pointer.
+constexpr int64_t STATIC_MAX_PIXELS = 1 << 20;   // largest image of the static entry point: 1 Mi pixels (e.g. 1024 x 1024)
+constexpr int64_t STATIC_CHUNK_RAYS = 1 << 16;   // rays traced and drawn per kernel pair
+constexpr size_t STATIC_OFF_LINES = 256;         // [0, 256): counters (u64 lines drawn)
+constexpr size_t STATIC_OFF_COV = STATIC_OFF_LINES + sizeof(double) * 5 * (size_t)STATIC_CHUNK_RAYS;
+constexpr size_t STATIC_SCRATCH_BYTES = STATIC_OFF_COV + sizeof(float) * 2 * (size_t)STATIC_MAX_PIXELS;
+static __device__ __align__(256) unsigned char scratch[STATIC_SCRATCH_BYTES];
+
 namespace {
 
 thread_local std::string g_err;
+
+// Device address of `scratch` on each GPU (every GPU holds its own copy at its own address), filled by the first
+// rt_ctx_create on that GPU.
+constexpr int MAX_DEVICES = 64;
+std::mutex g_scratch_mutex;
+void *g_scratch_ptr[MAX_DEVICES] = {};
 
 int32_t fail(int32_t code, const char *fmt, ...)
 {
@@ -81,6 +100,7 @@ struct rt_ctx {
     void *acc = nullptr;
     size_t acc_bytes = 0;
     int live_scenes = 0; // scenes created on this context and not yet destroyed
+    void *scratch = nullptr; // this device's copy of the static scratch array (see STATIC_SCRATCH_BYTES)
     // resident workgroups per CU of the three render2d_kernel instantiations on this device, as the runtime computes
     // them from the kernel's registers and LDS (0 = not asked yet)
     int per_cu2d[3] = { 0, 0, 0 };
@@ -228,6 +248,16 @@ int32_t rt_ctx_create(int32_t device_id, rt_ctx **out)
         HIP_TRY(hipMalloc((void **)&ctx->d_rays, 2 * sizeof(unsigned long long)));
         HIP_TRY(hipMemset(ctx->d_rays, 0, 2 * sizeof(unsigned long long)));
         HIP_TRY(hipDeviceGetAttribute(&ctx->n_cu, hipDeviceAttributeMultiprocessorCount, ctx->device));
+        if (device_id < MAX_DEVICES) {
+            // once per device, with that device current: where this GPU's copy of the static scratch array lives
+            std::lock_guard<std::mutex> lock(g_scratch_mutex);
+            if (!g_scratch_ptr[device_id]) {
+                void *ptr = nullptr;
+                HIP_TRY(hipGetSymbolAddress((void **)&ptr, HIP_SYMBOL(scratch)));
+                g_scratch_ptr[device_id] = ptr;
+            }
+            ctx->scratch = g_scratch_ptr[device_id];
+        }
         return RT_OK;
     }();
     if (rc != RT_OK) { // nothing half-made is handed out or left behind
@@ -1219,6 +1249,57 @@ int32_t rt2d_forward_render(rt_ctx *ctx, const rt2d_scene *scene, const rt2d_for
     step(hipStreamSynchronize(ctx->stream), "synchronize");
     (void)hipFree(d);
     return rc;
+}
+
+int32_t rt2d_forward_accumulate_static(rt_ctx *ctx, const rt2d_scene *scene, const rt2d_forward_params *p, void *d_rgb,
+                                       void *d_weight, void *d_lines)
+{
+    if (int32_t rc = ctx_bind(ctx)) return rc;
+    if (!scene || scene->ctx != ctx) return fail(RT_E_INVALID, "scene does not belong to this context");
+    if (!p || !d_rgb || !d_weight) return fail(RT_E_INVALID, "null argument");
+    if (!ctx->scratch) return fail(RT_E_LIMIT, "device %d has no static scratch (device ids above %d are not served)", ctx->device, MAX_DEVICES - 1);
+    if (p->width <= 0 || p->height <= 0) return fail(RT_E_INVALID, "bad image size");
+    const int64_t npx = (int64_t)p->width * p->height;
+    if (npx > STATIC_MAX_PIXELS)
+        return fail(RT_E_LIMIT, "image of %lld pixels is beyond the static scratch's %lld; use rt2d_forward_accumulate", (long long)npx,
+                    (long long)STATIC_MAX_PIXELS);
+    if (p->rays_per_emitter < 0 || p->rays_per_emitter > (1 << 24)) return fail(RT_E_LIMIT, "rays_per_emitter must be in 0..2^24");
+    if (p->depth < 0 || p->depth > 4095) return fail(RT_E_LIMIT, "depth must be in 0..4095");
+    if (p->sample_offset < 0 || (int64_t)p->sample_offset + p->rays_per_emitter > 0x7fffffffLL) return fail(RT_E_INVALID, "sample range out of bounds");
+    if (scene->emitter_bad >= 0)
+        return fail(RT_E_INVALID, "object %d emits but is not a circle: the reference has no sample_out_ray for segments and strips",
+                    scene->emitter_bad);
+    const int64_t n = (int64_t)scene->emitters.size() * p->rays_per_emitter;
+    if (n > (1LL << 31)) return fail(RT_E_LIMIT, "more than 2^31 rays");
+    // everything below goes through the device address looked up at rt_ctx_create, never through the array's name
+    char *base = (char *)ctx->scratch;
+    unsigned long long *n_lines = (unsigned long long *)base;
+    double *lines = (double *)(base + STATIC_OFF_LINES);
+    float *cov = (float *)(base + STATIC_OFF_COV);
+    // the array keeps the last call's contents: the plane (as far as this image reaches) and the counter start at zero
+    HIP_TRY(hipMemsetAsync(n_lines, 0, sizeof(unsigned long long), ctx->stream));
+    HIP_TRY(hipMemsetAsync(cov, 0, sizeof(float) * 2 * (size_t)npx, ctx->stream));
+    if (n > 0) {
+        rt2d::SceneDev S{};
+        if (int32_t rc = filter_frame(ctx, scene, scene->lo, scene->hi, &S)) return rc; // every origin lies in the scene's box
+        for (int64_t first = 0; first < n; first += STATIC_CHUNK_RAYS) {
+            const int64_t m = std::min<int64_t>(STATIC_CHUNK_RAYS, n - first);
+            const unsigned blocks = (unsigned)((m + rtk::BLOCK - 1) / rtk::BLOCK);
+            hipLaunchKernelGGL(rtk::forward_trace_kernel, dim3(blocks), dim3(rtk::BLOCK), 0, ctx->stream, S, scene->d_emitters, first, m,
+                               p->rays_per_emitter, p->depth, p->sample_offset, (uint32_t)p->seed, (uint32_t)(p->seed >> 32), lines,
+                               ctx->d_rays);
+            HIP_TRY(hipGetLastError());
+            hipLaunchKernelGGL(rtk::forward_splat_kernel, dim3(blocks), dim3(rtk::BLOCK), 0, ctx->stream, lines, m, p->width, p->height,
+                               cov, n_lines);
+            HIP_TRY(hipGetLastError());
+        }
+        ctx->samples += (uint64_t)n;
+        hipLaunchKernelGGL(rtk::forward_merge_kernel, dim3((unsigned)((npx + rtk::BLOCK - 1) / rtk::BLOCK)), dim3(rtk::BLOCK), 0,
+                           ctx->stream, cov, npx, (float *)d_rgb, (float *)d_weight);
+        HIP_TRY(hipGetLastError());
+    }
+    if (d_lines) HIP_TRY(hipMemcpyAsync(d_lines, n_lines, sizeof(unsigned long long), hipMemcpyDeviceToDevice, ctx->stream));
+    return RT_OK;
 }
 
 int32_t rt2d_trace_batch(rt_ctx *ctx, const rt2d_scene *scene, int64_t n, const double *ox, const double *oy, const double *dx,
