@@ -125,6 +125,10 @@ typedef struct rt_stats {
     uint64_t samples;   /* top-level trace_ray calls */
     uint64_t launches;  /* trace-kernel launches */
     double kernel_ms;   /* summed duration of those launches, HIP events on the context's stream */
+    /* rt3d_render / rt3d_accumulate only - what the tree walk did, for pricing it: inner BVH nodes visited (each
+     * tests its two child boxes) and exact Sphere::hit evaluations (3d/src/rt.rs:71-118) after the filters */
+    uint64_t bvh_node_visits;
+    uint64_t sphere_tests;
 } rt_stats;
 
 typedef struct rt_ctx rt_ctx;

@@ -212,7 +212,8 @@ class Context:
     def stats(self):
         s = Stats()
         check(_ffi.lib().rt_ctx_get_stats(self._ctx, C.byref(s)))
-        return {"rays": s.rays, "samples": s.samples, "launches": s.launches, "kernel_ms": s.kernel_ms}
+        return {"rays": s.rays, "samples": s.samples, "launches": s.launches, "kernel_ms": s.kernel_ms,
+                "bvh_node_visits": s.bvh_node_visits, "sphere_tests": s.sphere_tests}
 
     def reset_stats(self):
         check(_ffi.lib().rt_ctx_reset_stats(self._ctx))

@@ -331,6 +331,14 @@ RT_DEV Hit nearest_hit(SceneK S, double ox, double oy, double dx, double dy, boo
         // cost.  Each lane walks its own bits and keeps the minimum of (key, pid) in registers.
         uint32_t mw = filter_word(n_circ, c32, segp, E, 0, P, fr, force) & (0xFFFFFFFFu << (32 - P));
         if (!active) mw = 0u;
+        RT_STAMP(prof, 1);
+#ifdef RT_PROF
+        {
+            int cnt = __popc(mw);
+            for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off);
+            prof.t[10] += (unsigned long long)cnt;
+        }
+#endif
         int64_t bk = 0x7fffffffffffffffLL;
         uint64_t bps = ~0ull;
         auto keep = [&](bool got, double t, int pid, int s) {
@@ -357,6 +365,9 @@ RT_DEV Hit nearest_hit(SceneK S, double ox, double oy, double dx, double dy, boo
                 pid = c.pid;
             }
             keep(got, t, pid, s);
+#ifdef RT_PROF
+            prof.t[11] += 1;
+#endif
         }
         while (__any(ms != 0u)) {
             const int s = __clz((int)ms) & 31;
@@ -371,7 +382,11 @@ RT_DEV Hit nearest_hit(SceneK S, double ox, double oy, double dx, double dy, boo
                 pid = g.pid;
             }
             keep(got, t, pid, s);
+#ifdef RT_PROF
+            prof.t[11] += 1;
+#endif
         }
+        RT_STAMP(prof, 2);
         Hit best;
         const bool found = bk != 0x7fffffffffffffffLL;
         best.t = found ? __longlong_as_double(bk ^ (int64_t)((uint64_t)(bk >> 63) >> 1)) : 0.0;

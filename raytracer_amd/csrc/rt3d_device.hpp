@@ -58,10 +58,31 @@ struct SceneDev {
     double pos[3], p00[3], du[3], dv[3];
 };
 
+// The kernels read the scene where it arrives - in the kernel-argument segment, constant address space - field by
+// field at the point of use: copied into a by-value struct every field is loaded into a scalar register at kernel
+// entry and stays live over the whole trace loop, and there are more of them than scalar registers (the by-value form
+// of these kernels spilled 49 (BVH) and 121 (linear scan) scalar registers, each costing a v_readlane per use).
+typedef const SceneDev __attribute__((address_space(4))) *SceneK;
+typedef const SpherePair __attribute__((address_space(4))) *K_SpherePair;
+
+// Cuts the compiler's view of where a scene pointer came from, so the loads behind it are issued after this point
+// (per phase of the loop) instead of being hoisted to the top and kept in registers across the phases.
+RT_DEV SceneK fresh(SceneK s)
+{
+    asm volatile("" : "+s"(s));
+    return s;
+}
+
 struct Hit {
     double t;
     int32_t slot; // < 0: miss
     int32_t sid;
+};
+
+// Work a launch did beyond counting rays, for pricing the tree walk: inner-node visits (each tests two child
+// boxes) and exact Sphere::hit evaluations.  Per lane; the kernels sum them over the wave at the end.
+struct Work {
+    uint32_t node_visits, sphere_tests;
 };
 
 // Exact Sphere::hit distance in the reference's operation order.
@@ -81,13 +102,14 @@ RT_DEV bool sphere_t(double ox, double oy, double oz, double dx, double dy, doub
     return false;
 }
 
-RT_DEV void consider(const SceneDev &S, int slot, double ox, double oy, double oz, double dx, double dy, double dz,
-                     Hit &best, int64_t &best_key)
+RT_DEV void consider(SceneK S, int slot, double ox, double oy, double oz, double dx, double dy, double dz,
+                     Hit &best, int64_t &best_key, Work &work)
 {
     double t;
-    if (sphere_t(ox, oy, oz, dx, dy, dz, S.cx[slot], S.cy[slot], S.cz[slot], S.r2[slot], t)) {
+    work.sphere_tests += 1;
+    if (sphere_t(ox, oy, oz, dx, dy, dz, S->cx[slot], S->cy[slot], S->cz[slot], S->r2[slot], t)) {
         const int64_t key = total_key(t);
-        const int sid = S.sid[slot];
+        const int sid = S->sid[slot];
         if (key < best_key || (key == best_key && sid < best.sid)) {
             best_key = key;
             best.t = t;
@@ -99,15 +121,15 @@ RT_DEV void consider(const SceneDev &S, int slot, double ox, double oy, double o
 
 // Phase-1 filter word over slots [lo, hi): the reference's products up to the
 // discriminant, then keep iff delta >= 0 (sign bit).  Never drops a hit.
-RT_DEV uint32_t filter_word(const SceneDev &S, int lo, int hi, double ox, double oy, double oz, double dx, double dy,
+RT_DEV uint32_t filter_word(SceneK S, int lo, int hi, double ox, double oy, double oz, double dx, double dy,
                             double dz, double a)
 {
     uint32_t acc = 0;
 #pragma unroll 2
     for (int s = lo; s < hi; ++s) {
-        const double ocx = S.cx[s] - ox, ocy = S.cy[s] - oy, ocz = S.cz[s] - oz;
+        const double ocx = S->cx[s] - ox, ocy = S->cy[s] - oy, ocz = S->cz[s] - oz;
         const double h = (dx * ocx + dy * ocy) + dz * ocz;
-        const double c = ((ocx * ocx + ocy * ocy) + ocz * ocz) - S.r2[s];
+        const double c = ((ocx * ocx + ocy * ocy) + ocz * ocz) - S->r2[s];
         const double delta = h * h - a * c;
         acc = __builtin_amdgcn_alignbit(acc, (uint32_t)~hi32(delta), 31);
     }
@@ -136,11 +158,11 @@ struct FilterRay3 {
     f32x2 pad;           // 128 eps (B + |u|_inf)^2, rounded up
 };
 
-RT_DEV FilterRay3 filter_ray(const SceneDev &S, double ox, double oy, double oz, double dx, double dy, double dz, bool &in_range)
+RT_DEV FilterRay3 filter_ray(SceneK S, double ox, double oy, double oz, double dx, double dy, double dz, bool &in_range)
 {
-    const double ux = ox - S.filt_m[0], uy = oy - S.filt_m[1], uz = oz - S.filt_m[2];
+    const double ux = ox - S->filt_m[0], uy = oy - S->filt_m[1], uz = oz - S->filt_m[2];
     in_range = __builtin_fabs(((dx * dx + dy * dy) + dz * dz) - 1.0) <= 0x1.0p-40;
-    const double reach = S.filt_B + __builtin_fmax(__builtin_fmax(__builtin_fabs(ux), __builtin_fabs(uy)), __builtin_fabs(uz));
+    const double reach = S->filt_B + __builtin_fmax(__builtin_fmax(__builtin_fabs(ux), __builtin_fabs(uy)), __builtin_fabs(uz));
     const float padf = (float)(reach * reach * (128.0 * 0x1.0p-24)) * 1.0001f;
     const float fx = (float)dx, fy = (float)dy, fz = (float)dz;
     const float kx = -(float)(uy * dz - uz * dy), ky = -(float)(uz * dx - ux * dz), kz = -(float)(ux * dy - uy * dx);
@@ -151,10 +173,10 @@ RT_DEV FilterRay3 filter_ray(const SceneDev &S, double ox, double oy, double oz,
     return f;
 }
 
-RT_DEV uint32_t filter_word32(const SceneDev &S, int lo, int hi, const FilterRay3 &f)
+RT_DEV uint32_t filter_word32(SceneK S, int lo, int hi, const FilterRay3 &f)
 {
     uint32_t acc = 0; // collects DROP bits (the sign of g)
-    auto pair = [&](const SpherePair *q) {
+    auto pair = [&](K_SpherePair q) {
         const f32x2 vx = q->vx, vy = q->vy, vz = q->vz, e = q->e;
         const f32x2 xx = __builtin_elementwise_fma(f.dz, vy, __builtin_elementwise_fma(-f.dy, vz, f.nkx));
         const f32x2 xy = __builtin_elementwise_fma(f.dx, vz, __builtin_elementwise_fma(-f.dz, vx, f.nky));
@@ -162,7 +184,7 @@ RT_DEV uint32_t filter_word32(const SceneDev &S, int lo, int hi, const FilterRay
         return __builtin_elementwise_fma(-xx, xx, __builtin_elementwise_fma(-xy, xy, __builtin_elementwise_fma(-xz, xz, e))) + f.pad;
     };
     int s = lo;
-    const SpherePair *q = S.f32p + (lo >> 1); // lo is a multiple of 32
+    K_SpherePair q = (K_SpherePair)S->f32p + (lo >> 1); // lo is a multiple of 32
 #pragma unroll 4
     for (; s + 2 <= hi; s += 2, ++q) {
         const f32x2 g = pair(q);
@@ -178,8 +200,8 @@ RT_DEV uint32_t filter_word32(const SceneDev &S, int lo, int hi, const FilterRay
 
 // Brute force over slots [first, last): same two-phase scheme as the 2d tracer.
 template <bool F32>
-RT_DEV void scan_range(const SceneDev &S, int first, int last, double ox, double oy, double oz, double dx, double dy,
-                       double dz, bool active, Hit &best, int64_t &best_key)
+RT_DEV void scan_range(SceneK S, int first, int last, double ox, double oy, double oz, double dx, double dy,
+                       double dz, bool active, Hit &best, int64_t &best_key, Work &work)
 {
     const double a = (dx * dx + dy * dy) + dz * dz;
     // the f32 filter serves the wave when the range is worth it and every active lane's direction is a unit vector
@@ -217,7 +239,7 @@ RT_DEV void scan_range(const SceneDev &S, int first, int last, double ox, double
             m1 = (w == 1) ? rest : m1;
             m2 = (w == 2) ? rest : m2;
             m3 = (w == 3) ? rest : m3;
-            consider(S, base + 64 * w + b, ox, oy, oz, dx, dy, dz, best, best_key);
+            consider(S, base + 64 * w + b, ox, oy, oz, dx, dy, dz, best, best_key, work);
         }
     }
 }
@@ -251,29 +273,30 @@ constexpr int BVH_STACK = 32;
 // BVH = true: the spheres kept out of the tree, then the tree.  A kernel is compiled for each so that neither
 // carries the other's registers.
 template <bool BVH>
-RT_DEV Hit nearest_hit(const SceneDev &S, double ox, double oy, double oz, double dx, double dy, double dz,
-                       bool active, int32_t *stack, int stack_stride)
+RT_DEV Hit nearest_hit(SceneK S, double ox, double oy, double oz, double dx, double dy, double dz,
+                       bool active, int32_t *stack, int stack_stride, Work &work)
 {
+    S = fresh(S);
     Hit best;
     best.t = 0.0;
     best.slot = -1;
     best.sid = 0x7fffffff;
     int64_t best_key = 0x7fffffffffffffffLL;
     if (!BVH) {
-        scan_range<true>(S, 0, S.n, ox, oy, oz, dx, dy, dz, active, best, best_key);
+        scan_range<true>(S, 0, S->n, ox, oy, oz, dx, dy, dz, active, best, best_key, work);
         return best;
     }
     // the spheres kept out of the tree are one or two (the ground): the exact test on every lane costs less than the
     // filter pass over eight mostly empty words and its mask bookkeeping (standalone scene: 31.2 -> 33.5 Grays/s)
-    if (S.n_always <= 4) {
+    if (S->n_always <= 4) {
         if (active)
-            for (int s = 0; s < S.n_always; ++s) consider(S, s, ox, oy, oz, dx, dy, dz, best, best_key);
+            for (int s = 0; s < S->n_always; ++s) consider(S, s, ox, oy, oz, dx, dy, dz, best, best_key, work);
     } else {
-        scan_range<false>(S, 0, S.n_always, ox, oy, oz, dx, dy, dz, active, best, best_key);
+        scan_range<false>(S, 0, S->n_always, ox, oy, oz, dx, dy, dz, active, best, best_key, work);
     }
-    if (S.n_nodes == 0) return best;
+    if (S->n_nodes == 0) return best;
     const float oxf = (float)ox, oyf = (float)oy, ozf = (float)oz;
-    const float pad = (__builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(oxf), __builtin_fabsf(oyf)), __builtin_fabsf(ozf)) + (float)S.box_scale) * 0x1.0p-21f;
+    const float pad = (__builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(oxf), __builtin_fabsf(oyf)), __builtin_fabsf(ozf)) + (float)S->box_scale) * 0x1.0p-21f;
     const float ol[3] = { oxf + pad, oyf + pad, ozf + pad }, oh[3] = { oxf - pad, oyf - pad, ozf - pad };
     const float id[3] = { 1.0f / (float)dx, 1.0f / (float)dy, 1.0f / (float)dz };
     // "while-while" traversal: every lane walks inner nodes until it stands on a leaf (or has nothing left); only
@@ -298,7 +321,8 @@ RT_DEV Hit nearest_hit(const SceneDev &S, double ox, double oy, double oz, doubl
     while (__any(node != NONE)) {
         while (__any(node >= 0)) {
             if (node >= 0) {
-                const BvhNode2 nd = S.nodes[node];
+                work.node_visits += 1;
+                const BvhNode2 nd = S->nodes[node];
                 float tn0, tn1;
                 bool h0 = box_interval(nd.lo[0], nd.hi[0], ol, oh, id, tn0);
                 bool h1 = box_interval(nd.lo[1], nd.hi[1], ol, oh, id, tn1);
@@ -322,7 +346,7 @@ RT_DEV Hit nearest_hit(const SceneDev &S, double ox, double oy, double oz, doubl
         if (node != NONE) { // a leaf: <= 2 spheres
             const int enc = ~node;
             const int first = enc >> 2, cnt = enc & 3;
-            for (int k = 0; k < cnt; ++k) consider(S, first + k, ox, oy, oz, dx, dy, dz, best, best_key);
+            for (int k = 0; k < cnt; ++k) consider(S, first + k, ox, oy, oz, dx, dy, dz, best, best_key, work);
             node = pop();
         }
     }
@@ -337,18 +361,18 @@ struct Path {
 };
 
 // Camera::get_ray for pixel (i, j), global sample index `gs`.
-RT_DEV void generate(const SceneDev &S, Path &p, int i, int j, uint32_t gs, int bounce_limit, uint32_t k0, uint32_t k1)
+RT_DEV void generate(SceneK S, Path &p, int i, int j, uint32_t gs, int bounce_limit, uint32_t k0, uint32_t k1)
 {
-    const uint32_t pix = (uint32_t)(S.width * j + i);
+    const uint32_t pix = (uint32_t)(S->width * j + i);
     const U4 w = philox4x32_10(pix, gs, 0xFFFFFFFFu, 0u, k0, k1);
     const double rx = u01(w.x, w.y) - 1.0 / 2.0, ry = u01(w.z, w.w) - 1.0 / 2.0;
     const double a = (double)i + rx, b = (double)j + ry;
-    const double vx = ((S.p00[0] + a * S.du[0]) + b * S.dv[0]) - S.pos[0];
-    const double vy = ((S.p00[1] + a * S.du[1]) + b * S.dv[1]) - S.pos[1];
-    const double vz = ((S.p00[2] + a * S.du[2]) + b * S.dv[2]) - S.pos[2];
+    const double vx = ((S->p00[0] + a * S->du[0]) + b * S->dv[0]) - S->pos[0];
+    const double vy = ((S->p00[1] + a * S->du[1]) + b * S->dv[1]) - S->pos[1];
+    const double vz = ((S->p00[2] + a * S->du[2]) + b * S->dv[2]) - S->pos[2];
     const double rl = rlen3(vx, vy, vz);
     p.dx = vx * rl; p.dy = vy * rl; p.dz = vz * rl;
-    p.ox = S.pos[0]; p.oy = S.pos[1]; p.oz = S.pos[2];
+    p.ox = S->pos[0]; p.oy = S->pos[1]; p.oz = S->pos[2];
     p.thr = 1.0f;
     p.left = bounce_limit;
     p.c0 = pix;
@@ -357,7 +381,7 @@ RT_DEV void generate(const SceneDev &S, Path &p, int i, int j, uint32_t gs, int 
 
 // Body of World::trace_ray after the nearest hit is known.  Returns true when the
 // path ended, with rgb = the colour the innermost call returned times 0.5^bounces.
-RT_DEV bool shade(const SceneDev &S, Path &p, const Hit &h, int bounce_limit, uint32_t k0, uint32_t k1, float rgb[3])
+RT_DEV bool shade(SceneK S, Path &p, const Hit &h, int bounce_limit, uint32_t k0, uint32_t k1, float rgb[3])
 {
     if (h.slot < 0) {
         const float a = 0.5f * ((float)p.dy + 1.0f);
@@ -374,7 +398,7 @@ RT_DEV bool shade(const SceneDev &S, Path &p, const Hit &h, int bounce_limit, ui
     }
     const int s = h.slot;
     const double hx = p.ox + p.dx * h.t, hy = p.oy + p.dy * h.t, hz = p.oz + p.dz * h.t;
-    double nx = hx - S.cx[s], ny = hy - S.cy[s], nz = hz - S.cz[s];
+    double nx = hx - S->cx[s], ny = hy - S->cy[s], nz = hz - S->cz[s];
     const double nl = rlen3(nx, ny, nz);
     nx = nx * nl; ny = ny * nl; nz = nz * nl;
     const uint32_t bounce = (uint32_t)(bounce_limit - p.left);

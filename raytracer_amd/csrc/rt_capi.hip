@@ -87,7 +87,8 @@ struct rt_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
-    unsigned long long *d_rays = nullptr; // [0] rays traced, [1] (as int32) the 2d render kernel's tile counter
+    // [0] rays traced, [1] (as int32) the render kernels' work-unit counter, [2] BVH inner-node visits, [3] exact sphere tests
+    unsigned long long *d_rays = nullptr;
     int n_cu = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending; // trace-kernel brackets not yet folded
     std::vector<std::pair<hipEvent_t, hipEvent_t>> free_events;
@@ -105,6 +106,8 @@ struct rt_ctx {
     // them from the kernel's registers and LDS (0 = not asked yet)
     int per_cu2d[3] = { 0, 0, 0 };
 };
+
+struct rt3d_scene; // per-scene occupancy of render3d_kernel lives in the scene: it depends on the tree's depth
 
 struct rt2d_scene {
     rt_ctx *ctx = nullptr;
@@ -138,6 +141,7 @@ struct rt3d_scene {
     void *blob = nullptr;
     rt3d::SceneDev dev{};
     int stack_levels = 1; // depth of the BVH: entries of the per-lane traversal stack
+    mutable int per_cu = 0; // resident workgroups of this scene's render kernel per CU (0 = not asked yet)
 };
 
 namespace {
@@ -245,8 +249,8 @@ int32_t rt_ctx_create(int32_t device_id, rt_ctx **out)
     const int32_t rc = [&]() -> int32_t {
         HIP_TRY(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
         ctx->stream = ctx->own_stream;
-        HIP_TRY(hipMalloc((void **)&ctx->d_rays, 2 * sizeof(unsigned long long)));
-        HIP_TRY(hipMemset(ctx->d_rays, 0, 2 * sizeof(unsigned long long)));
+        HIP_TRY(hipMalloc((void **)&ctx->d_rays, 4 * sizeof(unsigned long long)));
+        HIP_TRY(hipMemset(ctx->d_rays, 0, 4 * sizeof(unsigned long long)));
         HIP_TRY(hipDeviceGetAttribute(&ctx->n_cu, hipDeviceAttributeMultiprocessorCount, ctx->device));
         if (device_id < MAX_DEVICES) {
             // once per device, with that device current: where this GPU's copy of the static scratch array lives
@@ -315,9 +319,11 @@ int32_t rt_ctx_get_stats(rt_ctx *ctx, rt_stats *out)
     if (!out) return fail(RT_E_INVALID, "null out");
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     if (int32_t rc = fold_events(ctx, 0)) return rc;
-    unsigned long long rays = 0;
-    HIP_TRY(hipMemcpy(&rays, ctx->d_rays, sizeof rays, hipMemcpyDeviceToHost));
-    out->rays = rays;
+    unsigned long long c[4] = { 0, 0, 0, 0 };
+    HIP_TRY(hipMemcpy(c, ctx->d_rays, sizeof c, hipMemcpyDeviceToHost));
+    out->rays = c[0];
+    out->bvh_node_visits = c[2];
+    out->sphere_tests = c[3];
     out->samples = ctx->samples;
     out->launches = ctx->launches;
     out->kernel_ms = ctx->kernel_ms;
@@ -330,6 +336,7 @@ int32_t rt_ctx_reset_stats(rt_ctx *ctx)
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     if (int32_t rc = fold_events(ctx, 0)) return rc;
     HIP_TRY(hipMemset(ctx->d_rays, 0, sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(ctx->d_rays + 2, 0, 2 * sizeof(unsigned long long)));
     ctx->kernel_ms = 0.0;
     ctx->samples = 0;
     ctx->launches = 0;
@@ -1657,15 +1664,38 @@ int32_t rt3d_accumulate(rt_ctx *ctx, const rt3d_scene *scene, const rt3d_render_
     A.k0 = (uint32_t)p->seed; A.k1 = (uint32_t)(p->seed >> 32);
     A.out = (float *)d_rgb;
     A.ray_counter = ctx->d_rays;
+    A.tile_counter = reinterpret_cast<int32_t *>(ctx->d_rays + 1);
+    A.work_counter = ctx->d_rays + 2;
     A.refill_min = refill_threshold();
     const int64_t tiles = (int64_t)A.tiles_x * ((scene->dev.height + 7) / 8);
+    if (tiles > 0x7fffffffLL - 65536) return fail(RT_E_LIMIT, "too many tiles");
+    A.n_tiles = (int32_t)tiles;
+    {
+        // work units of 1024 items (16 samples of a tile's 64 pixels): small against a wave's share of the launch,
+        // large against the refill and flush rate
+        const int64_t total = (int64_t)rtk::TILE_PIXELS * p->spp;
+        int64_t unit_items = 1024;
+        unit_items = std::max<int64_t>(unit_items, ((total * tiles / (0x7fffffffLL - 65536) + 64) / 64) * 64); // unit ids fit an int
+        A.chunk = (int32_t)std::min<int64_t>(unit_items, total);
+        A.n_units = (int32_t)(tiles * ((total + A.chunk - 1) / A.chunk));
+    }
+    const size_t stack_bytes = 2 * sizeof(int32_t) * rtk::BLOCK * (size_t)scene->stack_levels;
+    void (*const kernel)(const rtk::Render3dArgs) = scene->dev.use_bvh ? rtk::render3d_kernel<true> : rtk::render3d_kernel<false>;
+    if (scene->per_cu == 0) {
+        int nb = 0;
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, rtk::BLOCK, stack_bytes));
+        scene->per_cu = std::max(nb, 1);
+        if (getenv("RT_AMD_VERBOSE")) fprintf(stderr, "[rt_amd] render3d: %d CUs x %d resident workgroups, %zu B of stack\n", ctx->n_cu, scene->per_cu, stack_bytes);
+    }
+    // persistent waves: as many workgroups as can be resident at once, never more waves than units
+    const int waves_per_block = rtk::BLOCK / 64;
+    const int64_t blocks = std::min<int64_t>(((int64_t)A.n_units + waves_per_block - 1) / waves_per_block, (int64_t)std::max(ctx->n_cu, 1) * scene->per_cu);
+    HIP_TRY(hipMemsetAsync(A.tile_counter, 0, sizeof(int32_t), ctx->stream));
     std::pair<hipEvent_t, hipEvent_t> ev;
     if (int32_t rc = fold_events(ctx, 256)) return rc;
     if (int32_t rc = event_pair(ctx, &ev)) return rc;
     HIP_TRY(hipEventRecord(ev.first, ctx->stream));
-    const size_t stack_bytes = 2 * sizeof(int32_t) * rtk::BLOCK * (size_t)scene->stack_levels;
-    if (scene->dev.use_bvh) hipLaunchKernelGGL(rtk::render3d_kernel<true>, dim3((unsigned)tiles), dim3(rtk::BLOCK), stack_bytes, ctx->stream, A);
-    else hipLaunchKernelGGL(rtk::render3d_kernel<false>, dim3((unsigned)tiles), dim3(rtk::BLOCK), stack_bytes, ctx->stream, A);
+    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(rtk::BLOCK), stack_bytes, ctx->stream, A);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(ev.second, ctx->stream));
     ctx->pending.push_back(ev);
