@@ -129,6 +129,10 @@ typedef struct rt_stats {
      * tests its two child boxes) and exact Sphere::hit evaluations (3d/src/rt.rs:71-118) after the filters */
     uint64_t bvh_node_visits;
     uint64_t sphere_tests;
+    /* nearest-hit searches actually run.  <= rays: the reference traces ONE ray per (pixel, sample) once per
+     * lambda-sample (2d/src/librt2d_reverse.rs:90-101), and those calls all begin with the same search on the same
+     * ray; rt2d_render / rt2d_accumulate / rt2d_compute_pixels run it once per pair and reuse the hit. */
+    uint64_t searches;
 } rt_stats;
 
 typedef struct rt_ctx rt_ctx;

@@ -66,7 +66,7 @@ class RenderParams3D(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("samples", C.c_uint64), ("launches", C.c_uint64), ("kernel_ms", C.c_double),
-                ("bvh_node_visits", C.c_uint64), ("sphere_tests", C.c_uint64)]
+                ("bvh_node_visits", C.c_uint64), ("sphere_tests", C.c_uint64), ("searches", C.c_uint64)]
 
 
 # every symbol include/rt_abi.h declares: name -> (restype, argtypes)

@@ -213,7 +213,7 @@ class Context:
         s = Stats()
         check(_ffi.lib().rt_ctx_get_stats(self._ctx, C.byref(s)))
         return {"rays": s.rays, "samples": s.samples, "launches": s.launches, "kernel_ms": s.kernel_ms,
-                "bvh_node_visits": s.bvh_node_visits, "sphere_tests": s.sphere_tests}
+                "bvh_node_visits": s.bvh_node_visits, "sphere_tests": s.sphere_tests, "searches": s.searches}
 
     def reset_stats(self):
         check(_ffi.lib().rt_ctx_reset_stats(self._ctx))

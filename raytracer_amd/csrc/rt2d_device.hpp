@@ -726,13 +726,22 @@ RT_DEV int lambda_bin(uint32_t pix, uint32_t gsample, uint32_t l, uint32_t k0, u
     return (int)(((uint64_t)r * (uint64_t)NBINS) >> 32);
 }
 
+// Wavelength bins of four lambda-samples of (pixel, global sample), one byte each: block q holds lambda-samples
+// 4 q - 2 .. 4 q + 1 in bytes 0 .. 3 (lambda-sample l is word (l + 2) % 4 of call 1 + (l + 2) / 4, as lambda_bin).
+RT_DEV uint32_t lambda_bins4(uint32_t pix, uint32_t gsample, uint32_t q, uint32_t k0, uint32_t k1)
+{
+    const U4 wl = philox4x32_10(pix, gsample, 0xFFFFFFFFu, 1u + q, k0, k1);
+    auto bin = [](uint32_t r) { return (uint32_t)(((uint64_t)r * (uint64_t)NBINS) >> 32); };
+    return bin(wl.x) | (bin(wl.y) << 8) | (bin(wl.z) << 16) | (bin(wl.w) << 24);
+}
+
 // Primary ray of (pixel, global sample) (librt2d_reverse.rs:88-94) - the reference draws ONE ray per sample and
-// traces it once per lambda-sample (:90-101) - plus the wavelength bins of its first min(n_lambda, 16)
-// lambda-samples, one byte each in li[4].  Philox counter (pixel, sample, 0xFFFFFFFF, call): call 0 = pixel
-// jitter, call 1 = direction angle (words 0, 1) and the first two wavelength draws, calls 2.. = four wavelength
-// draws each.
-RT_DEV void generate_pair(double &ox, double &oy, double &dx, double &dy, uint32_t li[4], int px, int py, int width,
-                          uint32_t gsample, int n_lambda, double px_to_world, uint32_t k0, uint32_t k1)
+// traces it once per lambda-sample (:90-101) - plus the wavelength bins of its first two lambda-samples in bytes
+// 2 and 3 of `bins` (block 0 of lambda_bins4: bytes 0 and 1 belong to the direction angle).  Philox counter
+// (pixel, sample, 0xFFFFFFFF, call): call 0 = pixel jitter, call 1 = direction angle (words 0, 1) and the first two
+// wavelength draws, calls 2.. = four wavelength draws each.
+RT_DEV void generate_primary(double &ox, double &oy, double &dx, double &dy, uint32_t &bins, int px, int py, int width,
+                             uint32_t gsample, double px_to_world, uint32_t k0, uint32_t k1)
 {
     const uint32_t pix = (uint32_t)(width * py + px);
     const U4 w = philox4x32_10(pix, gsample, 0xFFFFFFFFu, 0u, k0, k1);
@@ -743,19 +752,7 @@ RT_DEV void generate_pair(double &ox, double &oy, double &dx, double &dy, uint32
     oy = y * px_to_world;
     sincos2pi(u01(w1.x, w1.y), dy, dx);
     auto bin = [](uint32_t r) { return (uint32_t)(((uint64_t)r * (uint64_t)NBINS) >> 32); };
-    // lambda-samples 0, 1 are words 2, 3 of call 1; lambda-sample l >= 2 is word (l + 2) % 4 of call 1 + (l + 2) / 4
-    li[0] = bin(w1.z) | (bin(w1.w) << 8);
-    li[1] = li[2] = li[3] = 0u;
-    const int n = n_lambda < 16 ? n_lambda : 16;
-    for (int call = 2; 4 * (call - 1) - 2 < n; ++call) { // wave-uniform trip count
-        const U4 wl = philox4x32_10(pix, gsample, 0xFFFFFFFFu, (uint32_t)call, k0, k1);
-        const int l0 = 4 * (call - 1) - 2; // lambda-sample of word 0 of this call: 2, 6, 10, 14
-        const uint32_t b4 = bin(wl.x) | (bin(wl.y) << 8) | (bin(wl.z) << 16) | (bin(wl.w) << 24);
-        // bytes l0 .. l0 + 3 of the 16-byte table: l0 = 2 (mod 4), so they straddle two words
-        const int wi = l0 >> 2;
-        li[wi] |= b4 << 16;
-        if (wi + 1 < 4) li[wi + 1] |= b4 >> 16;
-    }
+    bins = (bin(w1.z) << 16) | (bin(w1.w) << 24);
 }
 
 } // namespace rt2d

@@ -87,8 +87,12 @@ struct rt_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
-    // [0] rays traced, [1] (as int32) the render kernels' work-unit counter, [2] BVH inner-node visits, [3] exact sphere tests
+    // [0] rays traced, [1] (as int32) the render kernels' work-unit counter, [2] BVH inner-node visits, [3] exact sphere
+    // tests, [4] rays of the 2d render kernel that reused the nearest hit of their pair's first lambda-sample
     unsigned long long *d_rays = nullptr;
+    // the 2d render kernel's pair slabs (rtk::PairSlab, one per resident wave), grow-only
+    void *pairs = nullptr;
+    size_t pairs_bytes = 0;
     int n_cu = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending; // trace-kernel brackets not yet folded
     std::vector<std::pair<hipEvent_t, hipEvent_t>> free_events;
@@ -249,8 +253,8 @@ int32_t rt_ctx_create(int32_t device_id, rt_ctx **out)
     const int32_t rc = [&]() -> int32_t {
         HIP_TRY(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
         ctx->stream = ctx->own_stream;
-        HIP_TRY(hipMalloc((void **)&ctx->d_rays, 4 * sizeof(unsigned long long)));
-        HIP_TRY(hipMemset(ctx->d_rays, 0, 4 * sizeof(unsigned long long)));
+        HIP_TRY(hipMalloc((void **)&ctx->d_rays, 8 * sizeof(unsigned long long)));
+        HIP_TRY(hipMemset(ctx->d_rays, 0, 8 * sizeof(unsigned long long)));
         HIP_TRY(hipDeviceGetAttribute(&ctx->n_cu, hipDeviceAttributeMultiprocessorCount, ctx->device));
         if (device_id < MAX_DEVICES) {
             // once per device, with that device current: where this GPU's copy of the static scratch array lives
@@ -284,6 +288,7 @@ int32_t rt_ctx_destroy(rt_ctx *ctx)
     for (auto &ev : ctx->free_events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     if (ctx->ws) (void)hipFree(ctx->ws);
     if (ctx->acc) (void)hipFree(ctx->acc);
+    if (ctx->pairs) (void)hipFree(ctx->pairs);
     if (ctx->d_rays) (void)hipFree(ctx->d_rays);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
@@ -319,9 +324,10 @@ int32_t rt_ctx_get_stats(rt_ctx *ctx, rt_stats *out)
     if (!out) return fail(RT_E_INVALID, "null out");
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     if (int32_t rc = fold_events(ctx, 0)) return rc;
-    unsigned long long c[4] = { 0, 0, 0, 0 };
+    unsigned long long c[5] = { 0, 0, 0, 0, 0 };
     HIP_TRY(hipMemcpy(c, ctx->d_rays, sizeof c, hipMemcpyDeviceToHost));
     out->rays = c[0];
+    out->searches = c[0] - c[4];
     out->bvh_node_visits = c[2];
     out->sphere_tests = c[3];
     out->samples = ctx->samples;
@@ -336,7 +342,7 @@ int32_t rt_ctx_reset_stats(rt_ctx *ctx)
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     if (int32_t rc = fold_events(ctx, 0)) return rc;
     HIP_TRY(hipMemset(ctx->d_rays, 0, sizeof(unsigned long long)));
-    HIP_TRY(hipMemset(ctx->d_rays + 2, 0, 2 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(ctx->d_rays + 2, 0, 3 * sizeof(unsigned long long)));
     ctx->kernel_ms = 0.0;
     ctx->samples = 0;
     ctx->launches = 0;
@@ -714,6 +720,23 @@ int32_t launch_render2d(rt_ctx *ctx, const rt2d_scene *scene, const rt2d_render_
         if (getenv("RT_AMD_VERBOSE")) fprintf(stderr, "[rt_amd] render2d: %d CUs x %d resident workgroups\n", ctx->n_cu, per_cu);
     }
     const int64_t blocks = std::min<int64_t>(((int64_t)A.n_units + waves_per_block - 1) / waves_per_block, (int64_t)std::max(ctx->n_cu, 1) * per_cu);
+    {
+        // one slab of 64 pairs per resident wave; launches on a context are ordered on its stream, so they share it
+        const size_t need = (size_t)blocks * waves_per_block * sizeof(rtk::PairSlab);
+        if (need > ctx->pairs_bytes) {
+            if (ctx->pairs) {
+                HIP_TRY(hipStreamSynchronize(ctx->stream));
+                HIP_TRY(hipFree(ctx->pairs));
+                ctx->pairs = nullptr;
+                ctx->pairs_bytes = 0;
+            }
+            const size_t want = std::max(need, (size_t)std::max(ctx->n_cu, 1) * 8 * waves_per_block * sizeof(rtk::PairSlab));
+            HIP_TRY(hipMalloc(&ctx->pairs, want));
+            ctx->pairs_bytes = want;
+        }
+        A.pairs = (rtk::PairSlab *)ctx->pairs;
+        A.shared_counter = ctx->d_rays + 4;
+    }
     HIP_TRY(hipMemsetAsync(A.tile_counter, 0, sizeof(int32_t), ctx->stream));
     if (list_mode) HIP_TRY(hipMemsetAsync(d_out, 0, sizeof(float) * (size_t)n_list * RT_NBINS, ctx->stream));
     std::pair<hipEvent_t, hipEvent_t> ev;

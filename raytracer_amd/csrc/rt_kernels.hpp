@@ -41,6 +41,8 @@ struct Render2dArgs {
     unsigned long long *ray_counter;
     int32_t *tile_counter; // next unit to hand out, zeroed before the launch
     int32_t refill_min; // refill dead lanes once at least this many are dead (1..64)
+    struct PairSlab *pairs;              // one per resident wave
+    unsigned long long *shared_counter;  // rays that reused the nearest hit of their pair's first lambda-sample
     unsigned long long *prof_out; // diagnostic builds only
 };
 
@@ -56,33 +58,50 @@ __global__ __launch_bounds__(BLOCK) void pad_radii_kernel(const rt2d::CircleX *_
     c32[k >> 1].e[k & 1] = f;
 }
 
-// Primary rays generated ahead of their use, one wave's worth at a time (see render2d_kernel).
-struct RayPool {
+// Per-wave LDS of render2d_kernel, 15 dwords per lane.  Between steps it is the pool of rays that have taken their
+// first bounce and wait for a free lane (rows 0..12: origin and direction as four doubles, collected factors,
+// wavelength bin | lambda-sample << 8, output row, Philox counter words); during an intake step, while it is empty,
+// the lanes park their own paths in it (all 15 rows).
+struct ItemPool {
     double ox[64], oy[64], dx[64], dy[64];
-    uint32_t row[64], c0[64], c1[64]; // output row; Philox counter words (pixel, global sample)
-    uint32_t li[64][4];               // wavelength bins of the first 16 lambda-samples, one byte each
+    float thr[64];
+    uint32_t meta[64], row[64], c0[64], c1[64];
+    uint32_t park_depth[64], park_c2[64];
+};
+
+// The (pixel, sample) pairs a wave is working through, in global memory (one slab per resident wave, written once
+// per 64 pairs and read once per further lambda-sample, coalesced): the primary ray, ITS nearest hit, and what names
+// the pair.  slot: >= 0 hit, -1 miss, -2 no pair in this position (beyond the image or the unit).
+struct PairSlab {
+    double ox[64], oy[64], dx[64], dy[64], t[64];
+    int32_t slot[64];
+    uint32_t row[64], c0[64], c1[64];
 };
 
 // ReverseRenderer::compute_pixel for every pixel of the image or list
 // (2d/src/librt2d_reverse.rs:80-110), fused with trace_ray (:112-262).
 //
-// Waves are persistent and independent: each pulls work units (a run of one tile's (pixel, sample,
-// lambda-sample) items) from a global counter, and its lanes pull items from a wave-private cursor.  A lane
-// whose path ended is refilled in place, from the next unit when the current one runs out, so lanes idle
-// only once, at the end of the launch.  Primary rays are not generated by the few lanes that happen to be
-// dead in a step (the generator - two Philox blocks and a sincos - would run at 45 % lane use in every step):
-// when the wave's pool is empty all 64 lanes generate the ray of one (pixel, sample) pair each into LDS, with
-// the wavelength bins of its lambda-samples (which share the ray, librt2d_reverse.rs:90-101), and dead lanes
-// pop (ray, lambda-sample) items from the pool.
-// Units are small enough (about 1 k items) that the waves finish within
-// a few percent of each other, and they are numbered run-major so that the waves working at the same time are
-// on different tiles.  A finished sample is added to its pixel's bin in HBM with a hardware f32 atomic
-// (the tile's 18 KB stay in L2 while a unit lasts); nothing but the candidate queues lives in LDS.
+// Waves are persistent and independent: each pulls work units (a run of one tile's (pixel, sample) pairs) from a
+// global counter.  A lane owns one path in registers; a lane whose path ended takes a waiting ray from the wave's
+// pool, so lanes idle only once, at the end of the launch.  A step of the wave - nearest hit, shading, the diffuse
+// direction, the bookkeeping of finished samples - advances either the lanes' own paths or, when the pool is empty
+// and a lane is free, takes in new work (an INTAKE step): the 64 lanes park their paths in LDS and run the same
+// step on 64 pairs at once, one lambda-sample of each, and the rays that go on after that first bounce fill the
+// pool.
+// The reference draws ONE ray per (pixel, sample) and traces it once per lambda-sample (:90-101): all those
+// trace_ray calls start with the same nearest-hit search on the same ray.  The intake step of a pair's first
+// lambda-sample runs that search (at full lane use) and keeps ray and hit in the wave's slab; the intake steps of
+// its other lambda-samples read them back and go straight to the shading, which is where the wavelength first
+// matters.  Same arithmetic on the same operands, so the hit is the one every call would have found; the ray
+// counter still counts every trace_ray invocation, the search counter what was actually searched.
+// Units are small enough (about 1 k items) that the waves finish within a few percent of each other, and they are
+// numbered run-major so that the waves working at the same time are on different tiles.  A finished sample is added
+// to its pixel's bin in HBM with a hardware f32 atomic (the tile's 18 KB stay in L2 while a unit lasts).
 template <bool SEGW, bool SMALL = false>
 __global__ __launch_bounds__(BLOCK, 6) void render2d_kernel(const Render2dArgs A)
 {
-    __shared__ rt2d::CoopLds coop[BLOCK / 64];
-    __shared__ RayPool pools[BLOCK / 64];
+    __shared__ rt2d::CoopLds coop[SMALL ? 1 : BLOCK / 64];
+    __shared__ ItemPool pools[BLOCK / 64];
     // the arguments are read in place (kernel-argument segment), see rt2d::SceneK
     typedef const Render2dArgs __attribute__((address_space(4))) *ArgsK;
     ArgsK Ak = (ArgsK)__builtin_amdgcn_kernarg_segment_ptr();
@@ -100,10 +119,13 @@ __global__ __launch_bounds__(BLOCK, 6) void render2d_kernel(const Render2dArgs A
     bool alive = false;
     bool exhausted = false; // wave-uniform: no unit left
     int tile = 0, cursor = 0, cursor_end = 0, tx = 0, ty = 0; // wave-uniform; the cursor counts pairs
-    int pool_pos = 0, pool_items = 0;                         // wave-uniform; items = pairs in the pool x lambda_samples
-    RayPool &pool = pools[tid >> 6];
-    uint32_t orow = 0; // row of `out` this lane's path adds to
-    unsigned long long nrays = 0;
+    int pool_pos = 0, pool_items = 0;                         // wave-uniform
+    int set_lambda = n_lambda; // wave-uniform: next lambda-sample of the pair set in the slab to take in (n_lambda: none left)
+    ItemPool &pool = pools[tid >> 6];
+    PairSlab &slab = Ak->pairs[blockIdx.x * (BLOCK / 64) + (tid >> 6)];
+    uint32_t orow = 0;     // row of `out` this lane's path adds to
+    uint32_t set_bins = 0; // wavelength bins of four consecutive lambda-samples of this lane's pair of the set, one byte each
+    uint32_t nrays = 0, nsearch = 0;
     Prof prof{};
 #ifdef RT_PROF
     prof.last = __builtin_amdgcn_s_memtime();
@@ -112,41 +134,41 @@ __global__ __launch_bounds__(BLOCK, 6) void render2d_kernel(const Render2dArgs A
     while (true) {
         asm volatile("" : "+s"(Ak)); // arguments are re-read where a step needs them, not held in registers across it
         RT_STAMP(prof, 4);
-        const uint64_t dead = __ballot(!alive);
-        const int ndead = __popcll(dead);
-        if ((!exhausted || pool_pos < pool_items) && (ndead >= Ak->refill_min || ndead == 64)) {
-            const int r = rank_in_mask(dead);
-            int given = 0; // dead lanes served so far in this step
-            for (int pass = 0; pass < 2; ++pass) {
+        // ---- free lanes take waiting rays; if none wait, this step takes in new work
+        bool intake = false; // wave-uniform
+        {
+            const uint64_t dead = __ballot(!alive);
+            const int ndead = __popcll(dead);
+            if (ndead >= Ak->refill_min || ndead == 64) {
                 const int avail = pool_items - pool_pos;
-                const int take = (ndead - given < avail) ? ndead - given : avail;
-                if (!alive && r >= given && r < given + take) {
-                    const int i = pool_pos + (r - given);
-                    const int j = (int)((__umulhi((uint32_t)i, Ak->ls_magic) + (uint32_t)i) >> Ak->ls_shift); // i / lambda_samples
-                    const int l = i - j * n_lambda;
-                    p.ox = pool.ox[j]; p.oy = pool.oy[j]; p.dx = pool.dx[j]; p.dy = pool.dy[j];
-                    orow = pool.row[j];
-                    p.c0 = pool.c0[j]; p.c1 = pool.c1[j];
-                    p.c2 = (uint32_t)l;
-                    p.li = (int)((pool.li[j][(l >> 2) & 3] >> (8 * (l & 3))) & 0xFFu);
-                    p.thr = 1.0f;
-                    p.depth_left = Ak->recursion_limit;
-                }
-                if (n_lambda > 16) { // bins beyond the pool's table are drawn here (uniform branch)
-                    if (!alive && r >= given && r < given + take && p.c2 >= 16u) p.li = rt2d::lambda_bin(p.c0, p.c1, p.c2, Ak->k0, Ak->k1);
+                const int take = ndead < avail ? ndead : avail;
+                const int r = rank_in_mask(dead);
+                if (!alive && r < take) {
+                    const int i = pool_pos + r;
+                    p.ox = pool.ox[i]; p.oy = pool.oy[i]; p.dx = pool.dx[i]; p.dy = pool.dy[i];
+                    p.thr = pool.thr[i];
+                    const uint32_t m = pool.meta[i];
+                    p.li = (int)(m & 0xFFu);
+                    p.c2 = m >> 8;
+                    orow = pool.row[i];
+                    p.c0 = pool.c0[i]; p.c1 = pool.c1[i];
+                    p.depth_left = Ak->recursion_limit - 1;
+                    alive = true;
                 }
                 pool_pos += take;
-                given += take;
-                if (pass == 1 || given == ndead || exhausted) break;
-                // the pool ran dry: every lane generates the ray of one of the next 64 pairs
-                if (cursor >= cursor_end) {
-                    int t = 0;
-                    if (lane == 0) t = atomicAdd(Ak->tile_counter, 1);
-                    const int unit = __builtin_amdgcn_readfirstlane(t);
-                    if (unit >= Ak->n_units) {
-                        exhausted = true;
-                        break;
-                    }
+                intake = take < ndead && (set_lambda < n_lambda || !exhausted);
+            }
+        }
+        if (intake && set_lambda >= n_lambda) {
+            // the next 64 pairs: of this unit, or of the next one
+            if (cursor >= cursor_end) {
+                int t = 0;
+                if (lane == 0) t = atomicAdd(Ak->tile_counter, 1);
+                const int unit = __builtin_amdgcn_readfirstlane(t);
+                if (unit >= Ak->n_units) {
+                    exhausted = true;
+                    intake = false;
+                } else {
                     const int run = unit / Ak->n_tiles;
                     tile = unit - run * Ak->n_tiles;
                     cursor = run * Ak->chunk;
@@ -154,9 +176,31 @@ __global__ __launch_bounds__(BLOCK, 6) void render2d_kernel(const Render2dArgs A
                     tx = Ak->list_mode ? 0 : (tile % Ak->tiles_x) * TILE2D_W;
                     ty = Ak->list_mode ? 0 : (tile / Ak->tiles_x) * TILE2D_H;
                 }
+            }
+            if (intake) set_lambda = 0;
+        }
+        if (!intake && !__any(alive)) {
+            if (exhausted && set_lambda >= n_lambda && pool_pos >= pool_items) break;
+            continue;
+        }
+
+        // ---- an intake step works on lambda-sample `set_lambda` of the set's 64 pairs instead of the lanes' own paths
+        bool act = alive;        // lanes this step advances
+        bool have_hit = false;   // wave-uniform: the nearest hit comes from the slab
+        rt2d::Hit h;
+        h.t = 0.0; h.slot = -1; h.pid = 0x7fffffff;
+        if (intake) {
+            __builtin_amdgcn_wave_barrier();
+            pool.ox[lane] = p.ox; pool.oy[lane] = p.oy; pool.dx[lane] = p.dx; pool.dy[lane] = p.dy;
+            pool.thr[lane] = p.thr; pool.meta[lane] = (uint32_t)p.li; pool.row[lane] = orow;
+            pool.c0[lane] = p.c0; pool.c1[lane] = p.c1;
+            pool.park_depth[lane] = (uint32_t)p.depth_left; pool.park_c2[lane] = p.c2;
+            asm volatile("" ::: "memory");
+            bool valid;
+            if (set_lambda == 0) {
                 const int pair = cursor + lane;
                 cursor += 64;
-                bool valid = pair < cursor_end;
+                valid = pair < cursor_end;
                 int px = 0, py = 0;
                 int64_t row = 0;
                 const int s = pair / TILE2D_PIXELS;
@@ -173,36 +217,46 @@ __global__ __launch_bounds__(BLOCK, 6) void render2d_kernel(const Render2dArgs A
                     valid = valid && px < Ak->width && py < Ak->height;
                     row = (int64_t)Ak->width * py + px;
                 }
-                double gox, goy, gdx, gdy;
-                uint32_t gli[4];
+                valid = valid && Ak->recursion_limit > 0; // depth 0: trace_ray returns 0 before anything else (:120-122)
                 const uint32_t gs = (uint32_t)(Ak->sample_offset + s);
-                rt2d::generate_pair(gox, goy, gdx, gdy, gli, px, py, Ak->width, gs, n_lambda, Ak->px_to_world, Ak->k0, Ak->k1);
-                const uint64_t vm = __ballot(valid);
-                __builtin_amdgcn_wave_barrier();
-                if (valid) {
-                    const int j = rank_in_mask(vm);
-                    pool.ox[j] = gox; pool.oy[j] = goy; pool.dx[j] = gdx; pool.dy[j] = gdy;
-                    pool.row[j] = (uint32_t)row;
-                    pool.c0[j] = (uint32_t)(Ak->width * py + px); pool.c1[j] = gs;
-                    pool.li[j][0] = gli[0]; pool.li[j][1] = gli[1]; pool.li[j][2] = gli[2]; pool.li[j][3] = gli[3];
-                }
-                __builtin_amdgcn_wave_barrier();
-                pool_pos = 0;
-                pool_items = __popcll(vm) * n_lambda;
+                rt2d::generate_primary(p.ox, p.oy, p.dx, p.dy, set_bins, px, py, Ak->width, gs, Ak->px_to_world, Ak->k0, Ak->k1);
+                orow = (uint32_t)row;
+                p.c0 = (uint32_t)(Ak->width * py + px);
+                p.c1 = gs;
+            } else {
+                have_hit = true;
+                p.ox = slab.ox[lane]; p.oy = slab.oy[lane]; p.dx = slab.dx[lane]; p.dy = slab.dy[lane];
+                h.t = slab.t[lane];
+                h.slot = slab.slot[lane];
+                orow = slab.row[lane];
+                p.c0 = slab.c0[lane]; p.c1 = slab.c1[lane];
+                valid = h.slot != -2;
+                // lambda-sample l draws word (l + 2) % 4 of Philox call 1 + (l + 2) / 4 of the pair's stream
+                if (((set_lambda + 2) & 3) == 0) set_bins = rt2d::lambda_bins4(p.c0, p.c1, (uint32_t)(set_lambda + 2) >> 2, Ak->k0, Ak->k1);
             }
-            alive = alive || (r < given && !alive);
+            p.thr = 1.0f;
+            p.li = (int)((set_bins >> (8 * ((set_lambda + 2) & 3))) & 0xFFu);
+            p.c2 = (uint32_t)set_lambda;
+            p.depth_left = Ak->recursion_limit;
+            act = valid;
         }
-        if (!__any(alive)) {
-            if (exhausted && pool_pos >= pool_items) break;
-            continue;
-        }
-        const bool run = alive && p.depth_left > 0;
+        const bool run = act && p.depth_left > 0;
         RT_STAMP(prof, 0);
 #ifdef RT_PROF
         prof.t[5] += 1;
         prof.t[6] += (unsigned long long)__popcll(__ballot(run));
 #endif
-        const rt2d::Hit h = rt2d::nearest_hit<SEGW, SMALL>((rt2d::SceneK)&Ak->S, p.ox, p.oy, p.dx, p.dy, run, coop[tid >> 6], prof);
+        if (!have_hit) {
+            h = rt2d::nearest_hit<SEGW, SMALL>((rt2d::SceneK)&Ak->S, p.ox, p.oy, p.dx, p.dy, run, coop[SMALL ? 0 : (tid >> 6)], prof);
+            if (run) ++nsearch;
+            if (intake) {
+                slab.ox[lane] = p.ox; slab.oy[lane] = p.oy; slab.dx[lane] = p.dx; slab.dy[lane] = p.dy;
+                slab.t[lane] = h.t;
+                slab.slot[lane] = act ? h.slot : -2;
+                slab.row[lane] = orow;
+                slab.c0[lane] = p.c0; slab.c1[lane] = p.c1;
+            }
+        }
         float value = 0.0f;
         double dnx = 0.0, dny = 0.0;
         rt2d::ShadeResult r = rt2d::SHADE_DONE;
@@ -215,7 +269,7 @@ __global__ __launch_bounds__(BLOCK, 6) void render2d_kernel(const Render2dArgs A
         rt2d::rand_hemisphere_wave(run && r == rt2d::SHADE_DIFFUSE, dnx, dny, p.c0, p.c1, p.c2, bounce_idx, Ak->k0, Ak->k1, p.dx,
                                    p.dy, prof);
         RT_STAMP(prof, 13);
-        if (alive) {
+        if (act) {
             if (r == rt2d::SHADE_DONE) {
                 if (value != 0.0f) {
                     // per-sample term of `spectrum_spp / lambda_samples * 95` (librt2d_reverse.rs:104-105)
@@ -223,10 +277,35 @@ __global__ __launch_bounds__(BLOCK, 6) void render2d_kernel(const Render2dArgs A
                     const float c = v / inv_scale_l * (float)NBINS;
                     unsafeAtomicAdd(Ak->out + (int64_t)orow * NBINS + p.li, c);
                 }
-                alive = false;
+                act = false;
             } else if (p.depth_left == 0) {
-                alive = false; // the recursive call returns 0 at depth 0 (:120-122)
+                act = false; // the recursive call returns 0 at depth 0 (:120-122)
             }
+        }
+        if (intake) {
+            // the rays that go on wait in the pool; the lanes take their own paths back
+            const double nox = p.ox, noy = p.oy, ndx = p.dx, ndy = p.dy;
+            const float nthr = p.thr;
+            const uint32_t nmeta = (uint32_t)p.li | (p.c2 << 8), nrow = orow, nc0 = p.c0, nc1 = p.c1;
+            asm volatile("" ::: "memory");
+            p.ox = pool.ox[lane]; p.oy = pool.oy[lane]; p.dx = pool.dx[lane]; p.dy = pool.dy[lane];
+            p.thr = pool.thr[lane]; p.li = (int)pool.meta[lane]; orow = pool.row[lane];
+            p.c0 = pool.c0[lane]; p.c1 = pool.c1[lane];
+            p.depth_left = (int)pool.park_depth[lane]; p.c2 = pool.park_c2[lane];
+            const uint64_t cont = __ballot(act);
+            __builtin_amdgcn_wave_barrier();
+            if (act) {
+                const int j = rank_in_mask(cont);
+                pool.ox[j] = nox; pool.oy[j] = noy; pool.dx[j] = ndx; pool.dy[j] = ndy;
+                pool.thr[j] = nthr; pool.meta[j] = nmeta; pool.row[j] = nrow;
+                pool.c0[j] = nc0; pool.c1[j] = nc1;
+            }
+            __builtin_amdgcn_wave_barrier();
+            pool_pos = 0;
+            pool_items = __popcll(cont);
+            set_lambda += 1;
+        } else {
+            alive = act;
         }
         RT_STAMP(prof, 3);
     }
@@ -235,9 +314,16 @@ __global__ __launch_bounds__(BLOCK, 6) void render2d_kernel(const Render2dArgs A
         for (int i = 0; i < 16; ++i) atomicAdd(Ak->prof_out + i, prof.t[i]);
 #endif
 
-    // rays traced by this wave -> one global atomic
-    for (int off = 32; off > 0; off >>= 1) nrays += __shfl_down(nrays, off);
-    if (lane == 0 && nrays != 0) atomicAdd(Ak->ray_counter, nrays);
+    // rays traced by this wave, and how many of them skipped the search -> one global atomic each
+    unsigned long long nr = nrays, ns = nsearch;
+    for (int off = 32; off > 0; off >>= 1) {
+        nr += __shfl_down(nr, off);
+        ns += __shfl_down(ns, off);
+    }
+    if (lane == 0 && nr != 0) {
+        atomicAdd(Ak->ray_counter, nr);
+        if (nr != ns) atomicAdd(Ak->shared_counter, nr - ns);
+    }
 }
 
 // out[i] = out[i] / spp: `total_spectrum / spp` of compute_pixel (2d/src/librt2d_reverse.rs:109) for the pixel-list entry.

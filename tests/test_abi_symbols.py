@@ -40,7 +40,7 @@ def test_struct_layouts_match_the_header():
     assert ctypes.sizeof(_ffi.Material2D) == 48
     assert ctypes.sizeof(_ffi.RenderParams2D) == 40
     assert ctypes.sizeof(_ffi.RenderParams3D) == 24
-    assert ctypes.sizeof(_ffi.Stats) == 48
+    assert ctypes.sizeof(_ffi.Stats) == 56
     assert ctypes.sizeof(_ffi.Scene2DDesc) == 16 + 15 * 8
     assert ctypes.sizeof(_ffi.Scene3DDesc) == 8 + 4 * 8 + 9 * 8 + 8 + 8
 

@@ -37,7 +37,7 @@ def main():
         st = ctx.stats()
         P = world.n_prims
         print(json.dumps({"config": f"2d {name} {W}x{H} spp {spp * passes} lambda_samples {ls} depth 10", "primitives": P,
-                          "kernel_ms": st["kernel_ms"], "rays": st["rays"], "samples": st["samples"],
+                          "kernel_ms": st["kernel_ms"], "rays": st["rays"], "samples": st["samples"], "searches": st["searches"],
                           "Mrays_per_s": st["rays"] / st["kernel_ms"] / 1e3, "Msamples_per_s": st["samples"] / st["kernel_ms"] / 1e3,
                           "algorithmic_TFLOPs": st["rays"] * (15.0 * P + 60.0) / st["kernel_ms"] / 1e9,
                           # both roofline fractions: algorithmic FLOP against the 78.6 TFLOP/s f64 vector peak, and the
