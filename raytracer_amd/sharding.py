@@ -18,3 +18,13 @@ def sample_offset(step, rank, world_size, spp_per_step):
 
 def total_spp(steps, world_size, spp_per_step):
     return steps * world_size * spp_per_step
+
+
+def strong_range(rank, world_size, total_samples):
+    """Strong scaling: the fixed global sample range [0, total_samples) cut into world_size contiguous parts, the
+    first total_samples % world_size of them one sample longer.  Returns this rank's [lo, hi)."""
+    if not (0 <= rank < world_size) or total_samples < 0:
+        raise ValueError("bad shard coordinates")
+    base, extra = divmod(total_samples, world_size)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)

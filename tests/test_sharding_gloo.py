@@ -78,3 +78,54 @@ def test_shard_offsets_partition_the_sample_range():
         assert sorted(covered) == list(range(total_spp(steps, world_size, spp)))
     with pytest.raises(ValueError):
         sample_offset(0, 2, 2, 64)
+
+
+def test_strong_ranges_partition_the_fixed_job():
+    from raytracer_amd.sharding import strong_range
+    for total in (4096, 4097, 7, 0):
+        for world_size in (1, 2, 3, 4, 8):
+            parts = [strong_range(r, world_size, total) for r in range(world_size)]
+            assert parts[0][0] == 0 and parts[-1][1] == total
+            assert all(a[1] == b[0] for a, b in zip(parts, parts[1:]))
+            sizes = [hi - lo for lo, hi in parts]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        strong_range(2, 2, 64)
+
+
+def _worker3d(rank, world_size, port, out_path):
+    """configs[4]'s 3d leg on CPU: every rank sums its contiguous sample range of the 3d image, one all-reduce adds the
+    f32[W*H][3] images (World::compute_pixel is a SUM over spp, 3d/src/rt.rs:239-246, so the image needs no division)."""
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    import raytracer_amd as rt
+    from raytracer_amd.api import params3d
+    from raytracer_amd.sharding import strong_range
+    from tests.oracle_ffi import Oracle
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world_size)
+    oracle = Oracle(os.path.join(ROOT, "oracle", "build", "librt_oracle.so"))
+    scene = rt.Standalone3D(32, 24, use_bvh=False)
+    total = 5                                   # odd on purpose: the parts differ in length
+    lo, hi = strong_range(rank, world_size, total)
+    img = oracle.render3d(scene, params3d(hi - lo, 10, seed=9, sample_offset=lo), threads=1)[0]
+    t = torch.from_numpy(np.ascontiguousarray(img, np.float32))
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    if rank == 0:
+        whole = oracle.render3d(scene, params3d(total, 10, seed=9), threads=1)[0]
+        np.savez(out_path, sharded=t.numpy(), whole=whole)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_sum_the_3d_image(tmp_path):
+    torch = pytest.importorskip("torch")
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "result3d.npz")
+    mp.spawn(_worker3d, args=(2, _free_port(), out), nprocs=2, join=True)
+    r = np.load(out)
+    assert r["whole"].any()
+    assert np.allclose(r["sharded"], r["whole"], rtol=1e-5, atol=1e-6)
