@@ -26,21 +26,22 @@ struct BvhNode {
     int32_t pad_;
 };
 
-// Traversal node, 64 B, one per inner build node: the boxes of BOTH children in f32 and what each child is.
+// Traversal node, 64 B, one per inner build node: the boxes of BOTH children in f32, component c of every field
+// belonging to child c (so one packed f32 instruction works on both boxes), and what each child is.
 // child >= 0: index of an inner node; child < 0: a leaf, ~child = first slot << 2 | count (count <= 2).
 // Slots are BVH leaf order; `sid` maps a slot back to the caller's sphere index.  Boxes are rounded
 // outward to f32 from boxes already padded by 1e-7 x scene scale; the traversal adds a per-ray pad and a
-// relative slack (see box_interval), so a sphere hit at distance t always lies inside [tn, tf] of every
+// relative slack (see box_intervals), so a sphere hit at distance t always lies inside [tn, tf] of every
 // ancestor box as computed here.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 struct BvhNode2 {
-    float lo[2][3], hi[2][3];
+    f32x2 lox, loy, loz, hix, hiy, hiz;
     int32_t child[2];
     int32_t pad_[2];
 };
 
 // Two spheres as the f32 filter reads them, each field holding the value of both (one scalar load and one address
 // per pair: with four separate arrays the loop's scalar side weighs as much as its vector side).
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 struct SpherePair { f32x2 vx, vy, vz, e; };
 
 struct SceneDev {
@@ -244,24 +245,31 @@ RT_DEV void scan_range(SceneK S, int first, int last, double ox, double oy, doub
     }
 }
 
-// Slab interval of a ray against a child box (method of 2d/src/aabb.rs:39-66, three axes) in f32, made
-// conservative in three steps: (1) the box is rounded outward on the host; (2) the origin enters as
-// ol = o + pad and oh = o - pad with pad = 2^-21 (|o|_inf + scene scale), which exceeds the error of rounding
-// o to f32 plus that of the f32 subtraction (<= 2^-23 |o| + 2^-24 scale), so lo - ol and hi - oh are below /
-// above the true differences; (3) 1/d carries a relative error <= 2^-23 and the product another 2^-24: the
-// bounds are moved apart by 2^-20 |t|.  Returns true iff the padded interval reaches t >= 0; tn is its lower
-// end.  NaN (0 * inf: origin on a slab plane of an axis-parallel ray) is dropped by min/max: conservative.
-RT_DEV bool box_interval(const float lo[3], const float hi[3], const float ol[3], const float oh[3], const float id[3],
-                         float &tn)
+// Slab intervals of a ray against the two child boxes of a node (method of 2d/src/aabb.rs:39-66, three axes) in f32,
+// both boxes per packed instruction, made conservative in three steps: (1) the boxes are rounded outward on the
+// host; (2) the origin enters as ol = o + pad and oh = o - pad with pad = 2^-21 (|o|_inf + scene scale), which exceeds
+// the error of rounding o to f32 plus that of the f32 subtraction (<= 2^-23 |o| + 2^-24 scale), so lo - ol and hi - oh
+// are below / above the true differences; (3) 1/d carries a relative error <= 2^-23 and the product another 2^-24: the
+// bounds are moved apart by 2^-20 |t| (one fused step each: a single rounding, well inside the slack).  hit[c] = the
+// padded interval of child c reaches t >= 0; tn[c] = its lower end.  NaN (0 * inf: origin on a slab plane of an
+// axis-parallel ray) is dropped by min/max: conservative.
+RT_DEV void box_intervals(const BvhNode2 &nd, const f32x2 ol[3], const f32x2 oh[3], const f32x2 id[3], f32x2 &tn, bool hit[2])
 {
-    const float tx1 = (lo[0] - ol[0]) * id[0], tx2 = (hi[0] - oh[0]) * id[0];
-    const float ty1 = (lo[1] - ol[1]) * id[1], ty2 = (hi[1] - oh[1]) * id[1];
-    const float tz1 = (lo[2] - ol[2]) * id[2], tz2 = (hi[2] - oh[2]) * id[2];
-    const float tmin = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(tx1, tx2), __builtin_fminf(ty1, ty2)), __builtin_fminf(tz1, tz2));
-    const float tmax = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(tx1, tx2), __builtin_fmaxf(ty1, ty2)), __builtin_fmaxf(tz1, tz2));
-    tn = tmin - __builtin_fabsf(tmin) * 0x1.0p-20f;
-    const float tf = tmax + __builtin_fabsf(tmax) * 0x1.0p-20f;
-    return tf >= __builtin_fmaxf(tn, 0.0f);
+    const f32x2 tx1 = (nd.lox - ol[0]) * id[0], tx2 = (nd.hix - oh[0]) * id[0];
+    const f32x2 ty1 = (nd.loy - ol[1]) * id[1], ty2 = (nd.hiy - oh[1]) * id[1];
+    const f32x2 tz1 = (nd.loz - ol[2]) * id[2], tz2 = (nd.hiz - oh[2]) * id[2];
+    f32x2 tmin, tmax;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        tmin[c] = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(tx1[c], tx2[c]), __builtin_fminf(ty1[c], ty2[c])), __builtin_fminf(tz1[c], tz2[c]));
+        tmax[c] = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(tx1[c], tx2[c]), __builtin_fmaxf(ty1[c], ty2[c])), __builtin_fmaxf(tz1[c], tz2[c]));
+    }
+    const f32x2 amin = { __builtin_fabsf(tmin.x), __builtin_fabsf(tmin.y) }, amax = { __builtin_fabsf(tmax.x), __builtin_fabsf(tmax.y) };
+    const f32x2 slack = { 0x1.0p-20f, 0x1.0p-20f };
+    tn = __builtin_elementwise_fma(-amin, slack, tmin);
+    const f32x2 tf = __builtin_elementwise_fma(amax, slack, tmax);
+    hit[0] = tf.x >= __builtin_fmaxf(tn.x, 0.0f);
+    hit[1] = tf.y >= __builtin_fmaxf(tn.y, 0.0f);
 }
 
 constexpr int BVH_STACK = 32;
@@ -297,8 +305,10 @@ RT_DEV Hit nearest_hit(SceneK S, double ox, double oy, double oz, double dx, dou
     if (S->n_nodes == 0) return best;
     const float oxf = (float)ox, oyf = (float)oy, ozf = (float)oz;
     const float pad = (__builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(oxf), __builtin_fabsf(oyf)), __builtin_fabsf(ozf)) + (float)S->box_scale) * 0x1.0p-21f;
-    const float ol[3] = { oxf + pad, oyf + pad, ozf + pad }, oh[3] = { oxf - pad, oyf - pad, ozf - pad };
-    const float id[3] = { 1.0f / (float)dx, 1.0f / (float)dy, 1.0f / (float)dz };
+    const f32x2 ol[3] = { f32x2{ oxf + pad, oxf + pad }, f32x2{ oyf + pad, oyf + pad }, f32x2{ ozf + pad, ozf + pad } };
+    const f32x2 oh[3] = { f32x2{ oxf - pad, oxf - pad }, f32x2{ oyf - pad, oyf - pad }, f32x2{ ozf - pad, ozf - pad } };
+    const float idx = 1.0f / (float)dx, idy = 1.0f / (float)dy, idz = 1.0f / (float)dz;
+    const f32x2 id[3] = { f32x2{ idx, idx }, f32x2{ idy, idy }, f32x2{ idz, idz } };
     // "while-while" traversal: every lane walks inner nodes until it stands on a leaf (or has nothing left); only
     // then does the wave run the exact sphere tests, all leaf-holding lanes together.  Running them inside the
     // inner loop would charge every iteration of the wave with the two f64 sphere tests of whichever lane happens
@@ -308,13 +318,24 @@ RT_DEV Hit nearest_hit(SceneK S, double ox, double oy, double oz, double dx, dou
     constexpr int NONE = (int)0x80000000;
     int sp = 0;
     int node = active ? 0 : NONE;
-    // next subtree from the stack whose interval still starts before the best hit (equal t may still win on index)
+    // the best hit so far as an f32 at or above it: a box whose interval starts beyond THAT starts beyond the hit
+    // (equal t may still win on index, so only strictly later boxes are dropped); +inf while there is no hit
+    float bt = __builtin_inff();
+    auto note_best = [&]() {
+        if (best.slot >= 0) {
+            float f = (float)best.t;
+            if ((double)f < best.t) f = __uint_as_float(__float_as_uint(f) + 1u); // best.t >= 0 here: next float up
+            bt = f;
+        }
+    };
+    note_best();
+    // next subtree from the stack whose interval still starts before the best hit
     auto pop = [&]() {
         while (sp > 0) {
             --sp;
             const int cand = stack[(2 * sp) * stack_stride];
             const float tc = __int_as_float(stack[(2 * sp + 1) * stack_stride]);
-            if (!(best.slot >= 0 && (double)tc > best.t)) return cand;
+            if (!(tc > bt)) return cand;
         }
         return NONE;
     };
@@ -323,18 +344,15 @@ RT_DEV Hit nearest_hit(SceneK S, double ox, double oy, double oz, double dx, dou
             if (node >= 0) {
                 work.node_visits += 1;
                 const BvhNode2 nd = S->nodes[node];
-                float tn0, tn1;
-                bool h0 = box_interval(nd.lo[0], nd.hi[0], ol, oh, id, tn0);
-                bool h1 = box_interval(nd.lo[1], nd.hi[1], ol, oh, id, tn1);
-                if (best.slot >= 0) {
-                    h0 = h0 && !((double)tn0 > best.t);
-                    h1 = h1 && !((double)tn1 > best.t);
-                }
+                f32x2 tn;
+                bool h[2];
+                box_intervals(nd, ol, oh, id, tn, h);
+                const bool h0 = h[0] && !(tn.x > bt), h1 = h[1] && !(tn.y > bt);
                 if (h0 && h1) {
-                    const bool first0 = tn0 <= tn1;
+                    const bool first0 = tn.x <= tn.y;
                     node = first0 ? nd.child[0] : nd.child[1];
                     stack[(2 * sp) * stack_stride] = first0 ? nd.child[1] : nd.child[0]; // depth is validated <= BVH_STACK on the host
-                    stack[(2 * sp + 1) * stack_stride] = __float_as_int(first0 ? tn1 : tn0);
+                    stack[(2 * sp + 1) * stack_stride] = __float_as_int(first0 ? tn.y : tn.x);
                     ++sp;
                 } else if (h0 || h1) {
                     node = h0 ? nd.child[0] : nd.child[1];
@@ -347,6 +365,7 @@ RT_DEV Hit nearest_hit(SceneK S, double ox, double oy, double oz, double dx, dou
             const int enc = ~node;
             const int first = enc >> 2, cnt = enc & 3;
             for (int k = 0; k < cnt; ++k) consider(S, first + k, ox, oy, oz, dx, dy, dz, best, best_key, work);
+            note_best();
             node = pop();
         }
     }
