@@ -70,12 +70,11 @@ struct ItemPool {
 };
 
 // The (pixel, sample) pairs a wave is working through, in global memory (one slab per resident wave, written once
-// per 64 pairs and read once per further lambda-sample, coalesced): the primary ray, ITS nearest hit, and what names
-// the pair.  slot: >= 0 hit, -1 miss, -2 no pair in this position (beyond the image or the unit).
+// per 64 pairs and read once per further lambda-sample, coalesced): the primary ray and ITS nearest hit
+// (slot >= 0, or -1 for a miss).  44 bytes per pair.
 struct PairSlab {
     double ox[64], oy[64], dx[64], dy[64], t[64];
     int32_t slot[64];
-    uint32_t row[64], c0[64], c1[64];
 };
 
 // ReverseRenderer::compute_pixel for every pixel of the image or list
@@ -196,41 +195,39 @@ __global__ __launch_bounds__(BLOCK, 6) void render2d_kernel(const Render2dArgs A
             pool.c0[lane] = p.c0; pool.c1[lane] = p.c1;
             pool.park_depth[lane] = (uint32_t)p.depth_left; pool.park_c2[lane] = p.c2;
             asm volatile("" ::: "memory");
-            bool valid;
+            // which pair this lane stands for: the same for every lambda-sample of the set, so it is recomputed
+            // rather than kept in the slab
+            const int pair = (set_lambda == 0 ? cursor : cursor - 64) + lane;
+            if (set_lambda == 0) cursor += 64;
+            bool valid = pair < cursor_end;
+            int px = 0, py = 0;
+            int64_t row = 0;
+            const int s = pair / TILE2D_PIXELS;
+            const int lp = pair - s * TILE2D_PIXELS;
+            if (Ak->list_mode) {
+                const int64_t k = (int64_t)tile * TILE2D_PIXELS + lp;
+                valid = valid && k < Ak->n_list;
+                px = valid ? Ak->list_px[k] : 0;
+                py = valid ? Ak->list_py[k] : 0;
+                row = k;
+            } else {
+                px = tx + lp % TILE2D_W;
+                py = ty + lp / TILE2D_W;
+                valid = valid && px < Ak->width && py < Ak->height;
+                row = (int64_t)Ak->width * py + px;
+            }
+            valid = valid && Ak->recursion_limit > 0; // depth 0: trace_ray returns 0 before anything else (:120-122)
+            const uint32_t gs = (uint32_t)(Ak->sample_offset + s);
+            orow = (uint32_t)row;
+            p.c0 = (uint32_t)(Ak->width * py + px);
+            p.c1 = gs;
             if (set_lambda == 0) {
-                const int pair = cursor + lane;
-                cursor += 64;
-                valid = pair < cursor_end;
-                int px = 0, py = 0;
-                int64_t row = 0;
-                const int s = pair / TILE2D_PIXELS;
-                const int lp = pair - s * TILE2D_PIXELS;
-                if (Ak->list_mode) {
-                    const int64_t k = (int64_t)tile * TILE2D_PIXELS + lp;
-                    valid = valid && k < Ak->n_list;
-                    px = valid ? Ak->list_px[k] : 0;
-                    py = valid ? Ak->list_py[k] : 0;
-                    row = k;
-                } else {
-                    px = tx + lp % TILE2D_W;
-                    py = ty + lp / TILE2D_W;
-                    valid = valid && px < Ak->width && py < Ak->height;
-                    row = (int64_t)Ak->width * py + px;
-                }
-                valid = valid && Ak->recursion_limit > 0; // depth 0: trace_ray returns 0 before anything else (:120-122)
-                const uint32_t gs = (uint32_t)(Ak->sample_offset + s);
                 rt2d::generate_primary(p.ox, p.oy, p.dx, p.dy, set_bins, px, py, Ak->width, gs, Ak->px_to_world, Ak->k0, Ak->k1);
-                orow = (uint32_t)row;
-                p.c0 = (uint32_t)(Ak->width * py + px);
-                p.c1 = gs;
             } else {
                 have_hit = true;
                 p.ox = slab.ox[lane]; p.oy = slab.oy[lane]; p.dx = slab.dx[lane]; p.dy = slab.dy[lane];
                 h.t = slab.t[lane];
                 h.slot = slab.slot[lane];
-                orow = slab.row[lane];
-                p.c0 = slab.c0[lane]; p.c1 = slab.c1[lane];
-                valid = h.slot != -2;
                 // lambda-sample l draws word (l + 2) % 4 of Philox call 1 + (l + 2) / 4 of the pair's stream
                 if (((set_lambda + 2) & 3) == 0) set_bins = rt2d::lambda_bins4(p.c0, p.c1, (uint32_t)(set_lambda + 2) >> 2, Ak->k0, Ak->k1);
             }
@@ -252,9 +249,7 @@ __global__ __launch_bounds__(BLOCK, 6) void render2d_kernel(const Render2dArgs A
             if (intake) {
                 slab.ox[lane] = p.ox; slab.oy[lane] = p.oy; slab.dx[lane] = p.dx; slab.dy[lane] = p.dy;
                 slab.t[lane] = h.t;
-                slab.slot[lane] = act ? h.slot : -2;
-                slab.row[lane] = orow;
-                slab.c0[lane] = p.c0; slab.c1[lane] = p.c1;
+                slab.slot[lane] = h.slot;
             }
         }
         float value = 0.0f;
