@@ -147,7 +147,7 @@ class Work2D:
         self.rgb = torch.empty(W * H * 3, dtype=torch.float32, device="cuda")
         self.xyz = None
         self.kernel = "render2d_kernel"
-        self.tag = tag or f"{scene_name}_{W}x{H}_l{ls}"
+        self.tag = tag or f"{scene_name}_{W}x{H}_s{spp}_l{ls}"
         self.hbm_bytes_per_launch = 2.0 * W * H * rt.NBINS * 4
         self.samples_per_pass = W * H * spp * ls
 
@@ -194,7 +194,7 @@ class Work3D:
         self.n_prims = self.host_scene.desc.n_spheres
         self.buf = torch.zeros(W * H * 3, dtype=torch.float32, device="cuda")
         self.kernel = "render3d_kernel<%s>" % ("true" if use_bvh else "false")
-        self.tag = tag or ("3d_bvh" if use_bvh else "3d_linear")
+        self.tag = tag or f"3d_{'bvh' if use_bvh else 'linear'}_{W}x{H}_s{spp}"
         self.hbm_bytes_per_launch = 2.0 * W * H * 3 * 4
         self.samples_per_pass = W * H * spp
 
@@ -347,6 +347,13 @@ def main():
             work.finish(total_spp(n_steps, world_size, work.spp), merge_fn)
         warm = lambda: run(args.warmup)  # noqa: E731
 
+    if world_size > 1:
+        # communicator set-up (the first collective of a process group builds its rings) stays outside the timed job
+        # whatever --warmup says: one reduction of the size the job's merge moves
+        n_merge = work.W * work.H * 3 if (work.kind != "2d" or args.merge == "xyz") else work.W * work.H * rt.NBINS
+        scratch = torch.zeros(n_merge, dtype=torch.float32, device="cuda")
+        reduce_sum(scratch)
+        del scratch
     if args.warmup:
         if strong:
             for _ in range(args.warmup):
