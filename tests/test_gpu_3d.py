@@ -75,3 +75,52 @@ def test_camera_must_be_normalised(gpu_ctx):
     s.desc.cam_dir[0] = 0.5
     with pytest.raises(rt.RtError):
         rt.Scene3D(gpu_ctx, s)
+
+
+@pytest.mark.parametrize("use_bvh", [False, True])
+def test_two_contexts_render_sample_ranges_that_sum_to_the_single_render(use_bvh, gpu_ctx, oracle):
+    """The sample-batch sharding of the 3d image on one device: two contexts (as two ranks would own) accumulate the
+    global sample ranges [0, n/2) and [n/2, n) into their own f32[W*H][3] buffers; their sum - what the all-reduce
+    produces - is the render of [0, n) by one context (World::compute_pixel is a sum over spp, 3d/src/rt.rs:239-246),
+    with the same number of rays, and both match the CPU checker."""
+    torch = pytest.importorskip("torch")
+    from raytracer_amd.sharding import strong_range
+    w, h, n = 48, 36, 7                                    # odd: the two parts differ in length
+    s = rt.Standalone3D(w, h, use_bvh=use_bvh)
+    parts, rays = [], 0
+    for rank in range(2):
+        ctx = rt.Context(0, stream=torch.cuda.current_stream().cuda_stream)
+        scene = rt.Scene3D(ctx, s)
+        lo, hi = strong_range(rank, 2, n)
+        buf = torch.zeros(w * h * 3, dtype=torch.float32, device="cuda")
+        scene.accumulate(params3d(hi - lo, 10, seed=6, sample_offset=lo), buf.data_ptr())
+        ctx.synchronize()
+        rays += ctx.stats()["rays"]
+        parts.append(buf)
+        scene.close()
+        ctx.close()
+    total = (parts[0] + parts[1]).cpu().numpy().reshape(h, w, 3)
+    scene = rt.Scene3D(gpu_ctx, s)
+    gpu_ctx.reset_stats()
+    whole = scene.render(params3d(n, 10, seed=6))
+    assert gpu_ctx.stats()["rays"] == rays
+    scene.close()
+    assert whole.any() and np.allclose(total, whole, rtol=1e-5, atol=1e-7)
+    oimg, orays = oracle.render3d(s, params3d(n, 10, seed=6))
+    assert orays == rays and np.allclose(total, oimg, rtol=1e-5, atol=1e-7)
+
+
+def test_walk_counters_describe_the_tree_walk(gpu_ctx):
+    """rt_stats.bvh_node_visits / sphere_tests: zero node visits for the linear scan, a few per ray for the BVH, and
+    every ray tests at least the sphere kept out of the tree (the ground)."""
+    for use_bvh in (False, True):
+        scene = rt.Scene3D(gpu_ctx, rt.Standalone3D(64, 48, use_bvh=use_bvh))
+        gpu_ctx.reset_stats()
+        scene.render(params3d(4, 10, seed=1))
+        st = gpu_ctx.stats()
+        scene.close()
+        assert st["rays"] > 0 and st["searches"] == st["rays"]
+        if use_bvh:
+            assert st["rays"] < st["bvh_node_visits"] < 20 * st["rays"] and st["rays"] <= st["sphere_tests"] < 10 * st["rays"]
+        else:
+            assert st["bvh_node_visits"] == 0 and st["sphere_tests"] > 0

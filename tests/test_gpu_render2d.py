@@ -167,3 +167,21 @@ def test_zero_depth_and_bad_params(gpu_ctx):
         kw.update(bad)
         with pytest.raises(rt.RtError):
             scene.global_render(params2d(**kw))
+
+
+def test_lambda_samples_share_their_primary_search_and_nothing_else(gpu_ctx, oracle):
+    """The lambda-samples of a (pixel, sample) pair trace ONE primary ray (librt2d_reverse.rs:90-101); the kernel
+    searches its nearest hit once.  rays (trace_ray invocations) must still equal the checker's count, which searches
+    every invocation; searches = rays - (lambda_samples - 1) x pairs whose ray was traced; spectra as the checker's."""
+    world = rt.World2D("complex_world", seed=1)
+    scene = rt.Scene2D(gpu_ctx, world)
+    for ls in (1, 2, 5, 19):
+        p = params2d(48, 36, 3, ls, 10, seed=8)
+        gpu_ctx.reset_stats()
+        _, _, spec = scene.global_render(p, want_spectrum=True)
+        st = gpu_ctx.stats()
+        _, _, ospec, orays = oracle.render2d(world, p, threads=4)
+        assert st["rays"] == orays
+        assert st["searches"] == orays - (ls - 1) * 48 * 36 * 3
+        assert np.allclose(spec, ospec, rtol=1e-4, atol=1e-6)
+    scene.close()
