@@ -23,6 +23,8 @@ def torch_stream(gpu_ctx):
 @pytest.mark.parametrize("name,w,h,spp,ls", [
     ("complex_world", 1920, 1080, 6, 2),    # configs[1]: stress test at 1080p
     ("cornell_box", 3840, 2160, 2, 16),     # configs[2]: dispersion at 4K, many wavelengths
+    ("cornell_box_absorption", 3840, 2160, 2, 16),   # configs[2]: Beer-Lambert absorption at 4K
+    ("complex_world", 3840, 2160, 2, 2),    # the stress test at the north-star target's size (3.15 GB spectral buffer)
 ])
 def test_full_size_sample_ranges_and_sampled_pixels(name, w, h, spp, ls, gpu_ctx, oracle, torch_stream):
     world = rt.World2D(name, seed=1)
