@@ -51,8 +51,9 @@ struct SceneDev {
     const double *cx, *cy, *cz, *r2;
     const int32_t *sid;
     const BvhNode2 *nodes;
-    // spheres as the f32 filter sees them (see filter_word32), one record per pair of slots: centre - frame centre,
-    // padded r^2 (+inf for a sphere the frame does not hold: always a candidate); an odd count's spare half is -inf
+    // spheres as the f32 filter sees them (see filter_word32), one record per pair of slots: v = centre - frame centre
+    // and e = |v|^2 - r^2 (1 + 2^-22) rounded down (-inf for a sphere the frame does not hold: always a candidate;
+    // +inf in an odd count's spare half: never one)
     const SpherePair *f32p;
     double filt_m[3], filt_B;
     double box_scale; // largest |coordinate| of a tree box
@@ -137,26 +138,29 @@ RT_DEV uint32_t filter_word(SceneK S, int lo, int hi, double ox, double oy, doub
     return acc << (32 - (hi - lo));
 }
 
-// The same decision in f32, two spheres per packed instruction, for rays with | |d|^2 - 1 | <= 2^-40.
-// By Lagrange's identity the reference's discriminant is
-//   delta = h^2 - a c = a r^2 - |oc x d|^2,
-// so a sphere can only be hit when |oc x d|^2 <= a r^2.  With m the frame centre, u = o - m (U = |u|_inf, any
-// size) and v = c - m (|v_i| <= B for every sphere the frame holds):
-//   oc x d = v x d - u x d,   the second term per ray (computed in f64, rounded once),
-// each component X_i two fused steps.  Errors of a computed component (eps = 2^-24): d and v rounded to f32
-// 4 eps B, the rounded per-ray term 2 eps U, the two fused steps eps (B + 2U) + eps (2B + 2U): within
-// eps (7B + 6U) of the true value, whose size is at most 2 (B + U).  The computed |oc x d|^2 therefore exceeds
-// the true one by less than 3 x 28 eps (B + U)^2, the fused subtractions from r^2 add less than
-// 36 eps (B + U)^2 + 3 eps r^2, a = 1 +- 2^-40 moves a r^2 by 2^-40 r^2, and the reference's own f64 rounding
-// of delta is many orders below.  With the stored e = r^2 (1 + 2^-22) and the per-ray pad 128 eps (B + U)^2,
-//   g = e + pad - |oc x d|^2 >= 0   whenever the reference's delta >= 0.
+// The same decision in f32, two spheres per packed instruction, for rays with | |d|^2 - 1 | <= 2^-40: the
+// reference's discriminant delta = h^2 - a c itself, expanded around the frame centre m so that the per-ray and the
+// per-sphere parts are computed once, in f64.  With u = o - m (U = |u|_inf, any size) and v = centre - m (|v_i| <= B
+// for every sphere the frame holds), oc = v - u and
+//   h = d . oc = d . v - (d . u),                     three fused steps on the per-ray -(d . u);
+//   c = |oc|^2 - r^2 = (|v|^2 - r^2) - 2 u . v + |u|^2,   three fused steps on (q + k), q per sphere, k = |u|^2 per ray;
+//   g = h^2 - c                                        one fused step:
+// 8 packed operations per pair + one v_alignbit per sphere (the cross-product form this replaces took 10, the f64 form
+// above 15 f64 operations per sphere).  Errors against the true delta (eps = 2^-24, |d_i| <= 1): h carries the rounded
+// d and v (4 eps B), the rounded per-ray term (2 eps U) and three steps (6 eps (B + U)): within 12 eps (B + U) of a value
+// of size <= 1.8 (B + U), so h^2 is within 42 eps (B + U)^2; c carries the centre's rounding (6 eps B (B + U)), the
+// rounded u in the cross term (6 eps B U), the rounded q and k (3 eps (B^2 + U^2)) and four steps of size <= 3 (B + U)^2:
+// within 27 eps (B + U)^2; the last step adds 6 eps (B + U)^2.  Together 75 eps (B + U)^2; a = 1 +- 2^-40 moves a c by
+// 2^-40 x 3 (B + U)^2 and the reference's own f64 rounding of delta is many orders below.  With the stored
+// q = |v|^2 - r^2 (1 + 2^-22) rounded DOWN and k = |u|^2 - 128 eps (B + U)^2 rounded DOWN,
+//   g >= 0   whenever the reference's delta >= 0.
 // A ray near the scene gets a thin pad; one that starts far away (a bounce off the ground plane's far side)
-// gets a wide one and more candidates, but never the f64 loop.  10 packed operations per pair + one
-// v_alignbit per sphere (the f64 form above: 15 f64 operations per sphere).
+// gets a wide one and more candidates, but never the f64 loop.
 struct FilterRay3 {
-    f32x2 dx, dy, dz;    // direction, each duplicated into both halves
-    f32x2 nkx, nky, nkz; // -(u x d)
-    f32x2 pad;           // 128 eps (B + |u|_inf)^2, rounded up
+    f32x2 dx, dy, dz;       // direction, each duplicated into both halves
+    f32x2 ndu;              // -(d . u)
+    f32x2 m2ux, m2uy, m2uz; // -2 u
+    f32x2 k;                // |u|^2 - pad, rounded down
 };
 
 RT_DEV FilterRay3 filter_ray(SceneK S, double ox, double oy, double oz, double dx, double dy, double dz, bool &in_range)
@@ -164,13 +168,17 @@ RT_DEV FilterRay3 filter_ray(SceneK S, double ox, double oy, double oz, double d
     const double ux = ox - S->filt_m[0], uy = oy - S->filt_m[1], uz = oz - S->filt_m[2];
     in_range = __builtin_fabs(((dx * dx + dy * dy) + dz * dz) - 1.0) <= 0x1.0p-40;
     const double reach = S->filt_B + __builtin_fmax(__builtin_fmax(__builtin_fabs(ux), __builtin_fabs(uy)), __builtin_fabs(uz));
-    const float padf = (float)(reach * reach * (128.0 * 0x1.0p-24)) * 1.0001f;
+    const double kd = ((ux * ux + uy * uy) + uz * uz) - reach * reach * (128.0 * 0x1.0p-24);
+    float kf = (float)kd;
+    if ((double)kf > kd) kf -= __builtin_fmaxf(__builtin_fabsf(kf) * 0x1.0p-23f, 0x1.0p-126f); // at least one ulp down
     const float fx = (float)dx, fy = (float)dy, fz = (float)dz;
-    const float kx = -(float)(uy * dz - uz * dy), ky = -(float)(uz * dx - ux * dz), kz = -(float)(ux * dy - uy * dx);
+    const float ndu = -(float)((dx * ux + dy * uy) + dz * uz);
+    const float ax = -2.0f * (float)ux, ay = -2.0f * (float)uy, az = -2.0f * (float)uz;
     FilterRay3 f;
     f.dx = f32x2{ fx, fx }; f.dy = f32x2{ fy, fy }; f.dz = f32x2{ fz, fz };
-    f.nkx = f32x2{ kx, kx }; f.nky = f32x2{ ky, ky }; f.nkz = f32x2{ kz, kz };
-    f.pad = f32x2{ padf, padf };
+    f.ndu = f32x2{ ndu, ndu };
+    f.m2ux = f32x2{ ax, ax }; f.m2uy = f32x2{ ay, ay }; f.m2uz = f32x2{ az, az };
+    f.k = f32x2{ kf, kf };
     return f;
 }
 
@@ -179,10 +187,9 @@ RT_DEV uint32_t filter_word32(SceneK S, int lo, int hi, const FilterRay3 &f)
     uint32_t acc = 0; // collects DROP bits (the sign of g)
     auto pair = [&](K_SpherePair q) {
         const f32x2 vx = q->vx, vy = q->vy, vz = q->vz, e = q->e;
-        const f32x2 xx = __builtin_elementwise_fma(f.dz, vy, __builtin_elementwise_fma(-f.dy, vz, f.nkx));
-        const f32x2 xy = __builtin_elementwise_fma(f.dx, vz, __builtin_elementwise_fma(-f.dz, vx, f.nky));
-        const f32x2 xz = __builtin_elementwise_fma(f.dy, vx, __builtin_elementwise_fma(-f.dx, vy, f.nkz));
-        return __builtin_elementwise_fma(-xx, xx, __builtin_elementwise_fma(-xy, xy, __builtin_elementwise_fma(-xz, xz, e))) + f.pad;
+        const f32x2 h = __builtin_elementwise_fma(f.dx, vx, __builtin_elementwise_fma(f.dy, vy, __builtin_elementwise_fma(f.dz, vz, f.ndu)));
+        const f32x2 c = __builtin_elementwise_fma(f.m2ux, vx, __builtin_elementwise_fma(f.m2uy, vy, __builtin_elementwise_fma(f.m2uz, vz, e + f.k)));
+        return __builtin_elementwise_fma(h, h, -c);
     };
     int s = lo;
     K_SpherePair q = (K_SpherePair)S->f32p + (lo >> 1); // lo is a multiple of 32

@@ -1615,18 +1615,22 @@ int32_t rt3d_scene_create(rt_ctx *ctx, const rt3d_scene_desc *d, rt3d_scene **ou
                     const double v[3] = { b.c[0] - S.filt_m[0], b.c[1] - S.filt_m[1], b.c[2] - S.filt_m[2] };
                     const bool inside = framed[(size_t)b.sid] && std::fabs(v[0]) <= S.filt_B && std::fabs(v[1]) <= S.filt_B &&
                                         std::fabs(v[2]) <= S.filt_B;
-                    const double e = b.r * b.r * (1.0 + 0x1.0p-22); // the pad is per ray
                     rt3d::SpherePair &q = H(f32p)[k >> 1];
                     const int h = k & 1;
-                    // outside the frame: a candidate for every ray (zero centre keeps inf - x^2 free of inf - inf)
-                    q.vx[h] = inside ? (float)v[0] : 0.0f; q.vy[h] = inside ? (float)v[1] : 0.0f; q.vz[h] = inside ? (float)v[2] : 0.0f;
-                    q.e[h] = inside ? std::nextafterf((float)e, INFINITY) : INFINITY;
+                    // outside the frame: a candidate for every ray (zero centre keeps the fused steps finite beside the -inf)
+                    const float fv[3] = { inside ? (float)v[0] : 0.0f, inside ? (float)v[1] : 0.0f, inside ? (float)v[2] : 0.0f };
+                    q.vx[h] = fv[0]; q.vy[h] = fv[1]; q.vz[h] = fv[2];
+                    // e = |v|^2 - r^2 (1 + 2^-22) from the ROUNDED centre the filter multiplies with, rounded down; the pad is per ray
+                    const double e = (((double)fv[0] * fv[0] + (double)fv[1] * fv[1]) + (double)fv[2] * fv[2]) - b.r * b.r * (1.0 + 0x1.0p-22);
+                    float ef = (float)e;
+                    if ((double)ef > e) ef = std::nextafterf(ef, -INFINITY);
+                    q.e[h] = inside ? ef : -INFINITY;
                     ++k;
                 }
             if (np2 > n) {
                 rt3d::SpherePair &q = H(f32p)[n >> 1];
                 q.vx[1] = q.vy[1] = q.vz[1] = 0.0f;
-                q.e[1] = -INFINITY;
+                q.e[1] = INFINITY;
             }
             if (!nodes.empty()) memcpy(H(nd), nodes.data(), sizeof(rt3d::BvhNode2) * nodes.size());
         }

@@ -11,6 +11,7 @@ BENCH="python3 $PWD/bench.py --steps 5 --warmup 1 --cpu-spp 0 --configs none $*"
 run() { # name, rocprof args...
   local name=$1; shift
   echo "== $TAG $name"
+  rm -rf "$OUT/$name"   # results of an earlier run under the same tag would be averaged in
   timeout -s KILL 120 rocprofv3 "$@" --output-format csv -d "$OUT/$name" -- $BENCH > "$OUT/$name.log" 2>&1
   local rc=$?
   echo "rc=$rc"; tail -c 300 "$OUT/$name.log"; echo
