@@ -4,7 +4,6 @@
 #include "../../include/rt_abi.h"
 
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
 
 #include <algorithm>
 #include <cmath>
@@ -772,8 +771,8 @@ int32_t launch_render2d(rt_ctx *ctx, const rt2d_scene *scene, const rt2d_render_
     return RT_OK;
 }
 
-// The selection half of ReverseRenderer::denoise (librt2d_reverse.rs:346-392) on device planes: noise keys, sort,
-// top fraction, dilation, pixel list.  Everything comes from the context's workspace in one request (no allocation
+// The selection half of ReverseRenderer::denoise (librt2d_reverse.rs:346-392) on device planes: noise keys, the
+// top fraction's threshold key, dilation, pixel list.  Everything comes from the context's workspace in one request (no allocation
 // once it has grown); the list and the buffer for its spectra are sized for the most the mask can hold.
 struct NoisyPixels {
     int32_t *lx = nullptr, *ly = nullptr; // device: listed pixel coordinates, out-of-image ones included
@@ -798,16 +797,12 @@ int32_t select_noisy_pixels(rt_ctx *ctx, int W, int H, float top, int32_t mask_s
     const int64_t side = 2 * (int64_t)m + 1;
     const int64_t max_list = std::min<int64_t>(n_cells, n_top * side * side);
     if (max_list > (1LL << 30)) return fail(RT_E_LIMIT, "more than 2^30 pixels to recompute");
-    size_t tmp_bytes = 0;
-    HIP_TRY(hipcub::DeviceRadixSort::SortKeysDescending(nullptr, tmp_bytes, (uint64_t *)nullptr, (uint64_t *)nullptr, (int)n, 0, 64,
-                                                        ctx->stream));
-    struct Plan { uint64_t *keys, *sorted; uint8_t *mask; unsigned long long *counter; char *tmp; int32_t *lx, *ly; float *spec; size_t bytes; };
+    struct Plan { uint64_t *keys; rtk::SelectState *sel; uint32_t *hist; uint8_t *mask; unsigned long long *counter; int32_t *lx, *ly; float *spec; size_t bytes; };
     auto plan = [&](char *base) {
         Carver c{ base };
         Plan q{};
-        q.keys = c.take<uint64_t>((size_t)n); q.sorted = c.take<uint64_t>((size_t)n);
+        q.keys = c.take<uint64_t>((size_t)n); q.sel = c.take<rtk::SelectState>(1); q.hist = c.take<uint32_t>(256);
         q.mask = c.take<uint8_t>((size_t)n_cells + 4); q.counter = c.take<unsigned long long>(1);
-        q.tmp = c.take<char>(tmp_bytes);
         q.lx = c.take<int32_t>((size_t)max_list); q.ly = c.take<int32_t>((size_t)max_list);
         q.spec = c.take<float>((size_t)max_list * RT_NBINS);
         q.bytes = c.off + 256;
@@ -820,11 +815,21 @@ int32_t select_noisy_pixels(rt_ctx *ctx, int W, int H, float top, int32_t mask_s
     const unsigned nb = (unsigned)((n + rtk::BLOCK - 1) / rtk::BLOCK);
     hipLaunchKernelGGL(rtk::denoise_keys_kernel, dim3(nb), dim3(rtk::BLOCK), 0, ctx->stream, d_merged_rgb, d_loop_rgb, W, H, q.keys);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipcub::DeviceRadixSort::SortKeysDescending(q.tmp, tmp_bytes, q.keys, q.sorted, (int)n, 0, 64, ctx->stream));
+    // the n_top-th largest key, a byte per pass (rt_kernels.hpp::select_count_kernel); the starting state travels
+    // as a kernel argument (a copy from this stack frame would have to be waited for)
+    const rtk::SelectState start{ 0ull, (uint64_t)n_top };
+    HIP_TRY(hipMemsetAsync(q.hist, 0, 256 * sizeof(uint32_t), ctx->stream));
+    hipLaunchKernelGGL(rtk::select_start_kernel, dim3(1), dim3(1), 0, ctx->stream, q.sel, start);
+    HIP_TRY(hipGetLastError());
+    const unsigned sb = std::min<unsigned>(nb, 1024u);
+    for (int shift = 56; shift >= 0; shift -= 8) {
+        hipLaunchKernelGGL(rtk::select_count_kernel, dim3(sb), dim3(rtk::BLOCK), 0, ctx->stream, q.keys, n, shift, q.sel, q.hist);
+        hipLaunchKernelGGL(rtk::select_pick_kernel, dim3(1), dim3(rtk::BLOCK), 0, ctx->stream, q.hist, q.sel, shift);
+    }
+    HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemsetAsync(q.mask, 0, (size_t)n_cells + 4, ctx->stream)); // the list kernel reads whole 4-byte words
     HIP_TRY(hipMemsetAsync(q.counter, 0, sizeof(unsigned long long), ctx->stream));
-    hipLaunchKernelGGL(rtk::denoise_mark_kernel, dim3((unsigned)((n_top + rtk::BLOCK - 1) / rtk::BLOCK)), dim3(rtk::BLOCK), 0,
-                       ctx->stream, q.sorted, n_top, W, m, q.mask);
+    hipLaunchKernelGGL(rtk::denoise_mark_kernel, dim3(nb), dim3(rtk::BLOCK), 0, ctx->stream, q.keys, n, q.sel, W, m, q.mask);
     HIP_TRY(hipGetLastError());
     const unsigned ncb = (unsigned)((n_cells + rtk::LIST_CELLS_PER_WAVE - 1) / rtk::LIST_CELLS_PER_WAVE);
     hipLaunchKernelGGL(rtk::denoise_list_kernel, dim3(ncb), dim3(64), 0, ctx->stream, q.mask, EW, n_cells, m, q.lx, q.ly,

@@ -654,16 +654,61 @@ __global__ __launch_bounds__(BLOCK) void denoise_keys_kernel(const float *__rest
     keys[idx] = ((uint64_t)__float_as_uint(key) << 32) | (uint64_t)(uint32_t)idx;
 }
 
+// The `top` pixels (librt2d_reverse.rs:368-378 sorts all keys and takes the first n_top) are the pixels whose key is
+// >= the n_top-th largest key; keys are distinct (they end in the pixel index), so that key alone names the set and
+// no order is needed.  It is found one byte at a time from the top: a pass counts, per value of the current byte,
+// the keys that agree with the bytes fixed so far (select_count_kernel: a histogram per workgroup in LDS, added to
+// the global one), then one workgroup fixes the byte whose bucket holds the wanted rank and lowers the rank by the
+// buckets above it (select_pick_kernel).  Eight passes over the 8 n bytes of keys; nothing returns to the host.
+struct SelectState {
+    uint64_t prefix; // the bytes fixed so far (the rest zero); after the last pass the n_top-th largest key itself
+    uint64_t want;   // rank, from the top and 1-based, of that key among the keys that agree with `prefix`
+};
+
+__global__ void select_start_kernel(SelectState *st, SelectState start) { *st = start; }
+
+__global__ __launch_bounds__(BLOCK) void select_count_kernel(const uint64_t *__restrict__ keys, int64_t n, int shift,
+                                                            const SelectState *__restrict__ st, uint32_t *__restrict__ hist)
+{
+    __shared__ uint32_t h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint64_t prefix = st->prefix;
+    const uint64_t fixed = shift == 56 ? 0ull : ~0ull << (shift + 8);
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
+        const uint64_t k = keys[i];
+        if ((k & fixed) == prefix) atomicAdd(&h[(k >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    if (h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], h[threadIdx.x]);
+}
+
+// One workgroup of 256: thread t owns bucket t; clears the histogram for the next pass.
+__global__ __launch_bounds__(BLOCK) void select_pick_kernel(uint32_t *__restrict__ hist, SelectState *__restrict__ st, int shift)
+{
+    __shared__ uint32_t h[256];
+    const int t = threadIdx.x;
+    h[t] = hist[t];
+    hist[t] = 0;
+    const uint64_t want = st->want, prefix = st->prefix; // read by every thread before the one write below
+    __syncthreads();
+    uint64_t above = 0;
+    for (int u = t + 1; u < 256; ++u) above += h[u];
+    if (above < want && want <= above + h[t]) {
+        st->prefix = prefix | ((uint64_t)t << shift);
+        st->want = want - above;
+    }
+}
+
 // The set of pixels to recompute (librt2d_reverse.rs:380-392): every top pixel marks its (2m+1)^2 neighbourhood
 // in a byte map over the image grown by m on every side (pixels outside the image are recomputed too, as in the
 // reference, and dropped when added).
-__global__ __launch_bounds__(BLOCK) void denoise_mark_kernel(const uint64_t *__restrict__ sorted_keys, int64_t n_top, int W, int m,
-                                                            uint8_t *__restrict__ mask)
+__global__ __launch_bounds__(BLOCK) void denoise_mark_kernel(const uint64_t *__restrict__ keys, int64_t n, const SelectState *__restrict__ st,
+                                                            int W, int m, uint8_t *__restrict__ mask)
 {
-    const int64_t k = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (k >= n_top) return;
-    const uint32_t idx = (uint32_t)sorted_keys[k];
-    const int x = (int)(idx % (uint32_t)W), y = (int)(idx / (uint32_t)W);
+    const int64_t idx = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (idx >= n || keys[idx] < st->prefix) return;
+    const int x = (int)((uint32_t)idx % (uint32_t)W), y = (int)((uint32_t)idx / (uint32_t)W);
     const int EW = W + 2 * m;
     for (int j = -m; j <= m; ++j)
         for (int i = -m; i <= m; ++i) mask[(int64_t)EW * (y + j + m) + (x + i + m)] = 1;
