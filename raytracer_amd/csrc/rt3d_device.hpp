@@ -35,7 +35,7 @@ struct BvhNode {
 // ancestor box as computed here.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 struct BvhNode2 {
-    f32x2 lox, loy, loz, hix, hiy, hiz;
+    f32x2 plane[6]; // lo x, hi x, lo y, hi y, lo z, hi z, each holding both children's value
     int32_t child[2];
     int32_t pad_[2];
 };
@@ -253,30 +253,55 @@ RT_DEV void scan_range(SceneK S, int first, int last, double ox, double oy, doub
 }
 
 // Slab intervals of a ray against the two child boxes of a node (method of 2d/src/aabb.rs:39-66, three axes) in f32,
-// both boxes per packed instruction, made conservative in three steps: (1) the boxes are rounded outward on the
-// host; (2) the origin enters as ol = o + pad and oh = o - pad with pad = 2^-21 (|o|_inf + scene scale), which exceeds
-// the error of rounding o to f32 plus that of the f32 subtraction (<= 2^-23 |o| + 2^-24 scale), so lo - ol and hi - oh
-// are below / above the true differences; (3) 1/d carries a relative error <= 2^-23 and the product another 2^-24: the
-// bounds are moved apart by 2^-20 |t| (one fused step each: a single rounding, well inside the slack).  hit[c] = the
-// padded interval of child c reaches t >= 0; tn[c] = its lower end.  NaN (0 * inf: origin on a slab plane of an
-// axis-parallel ray) is dropped by min/max: conservative.
-RT_DEV void box_intervals(const BvhNode2 &nd, const f32x2 ol[3], const f32x2 oh[3], const f32x2 id[3], f32x2 &tn, bool hit[2])
+// both boxes per packed instruction: with idf = 1 / (float) d, t = plane * idf + c in one fused step, where c =
+// -(float) o * idf -+ pad |idf| per ray and axis, minus for the plane the ray meets first (the low one when d >= 0).
+// Conservative in three steps: (1) the boxes are rounded outward on the host; (2) c's own error - o rounded to f32
+// and the fused step's rounding, together < 2.1 * 2^-24 |o| |idf| - is below a quarter of the pad
+// 2^-21 (|o|_inf + scene scale) |idf|, which moves the near bound down and the far bound up; (3) idf carries a relative
+// error <= 2^-23 and the step that forms t another 2^-24: the bounds are moved apart by 2^-20 |t| (one fused step each,
+// a single rounding, well inside the slack).  hit[c] = the padded interval of child c reaches t >= 0 and starts at or
+// before `bt`; tn[c] = its lower end.  NaN (0 * inf: origin on a slab plane of an axis-parallel ray) is dropped by
+// min / max: conservative.  (Fetching near and far planes by per-lane offsets instead - no min / max per axis - cuts
+// another 12 instructions and was slower, 27.5 against 32.4 Grays/s: seven divergent loads per visit instead of four.)
+struct BoxRay {
+    float idf[3], c_lo[3], c_hi[3];
+};
+
+RT_DEV BoxRay box_ray(double ox, double oy, double oz, double dx, double dy, double dz, float scale)
 {
-    const f32x2 tx1 = (nd.lox - ol[0]) * id[0], tx2 = (nd.hix - oh[0]) * id[0];
-    const f32x2 ty1 = (nd.loy - ol[1]) * id[1], ty2 = (nd.hiy - oh[1]) * id[1];
-    const f32x2 tz1 = (nd.loz - ol[2]) * id[2], tz2 = (nd.hiz - oh[2]) * id[2];
-    f32x2 tmin, tmax;
+    const float of[3] = { (float)ox, (float)oy, (float)oz };
+    const float df[3] = { (float)dx, (float)dy, (float)dz };
+    const float pad = (__builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(of[0]), __builtin_fabsf(of[1])), __builtin_fabsf(of[2])) + scale) * 0x1.0p-21f;
+    BoxRay r;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        r.idf[a] = 1.0f / df[a];
+        // pad * idf has the direction's sign: subtracting it lowers t on the low plane when that one is the near plane
+        // (d >= 0) and raises it when it is the far one
+        const float padt = pad * r.idf[a];
+        r.c_lo[a] = __builtin_fmaf(-of[a], r.idf[a], -padt);
+        r.c_hi[a] = __builtin_fmaf(-of[a], r.idf[a], padt);
+    }
+    return r;
+}
+
+RT_DEV void box_intervals(const BvhNode2 &nd, const BoxRay &r, float bt, f32x2 &tn, bool hit[2])
+{
+    f32x2 t1[3], t2[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        t1[a] = __builtin_elementwise_fma(nd.plane[2 * a], f32x2{ r.idf[a], r.idf[a] }, f32x2{ r.c_lo[a], r.c_lo[a] });
+        t2[a] = __builtin_elementwise_fma(nd.plane[2 * a + 1], f32x2{ r.idf[a], r.idf[a] }, f32x2{ r.c_hi[a], r.c_hi[a] });
+    }
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
-        tmin[c] = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(tx1[c], tx2[c]), __builtin_fminf(ty1[c], ty2[c])), __builtin_fminf(tz1[c], tz2[c]));
-        tmax[c] = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(tx1[c], tx2[c]), __builtin_fmaxf(ty1[c], ty2[c])), __builtin_fmaxf(tz1[c], tz2[c]));
+        const float lo = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(t1[0][c], t2[0][c]), __builtin_fminf(t1[1][c], t2[1][c])), __builtin_fminf(t1[2][c], t2[2][c]));
+        const float hi = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(t1[0][c], t2[0][c]), __builtin_fmaxf(t1[1][c], t2[1][c])), __builtin_fmaxf(t1[2][c], t2[2][c]));
+        tn[c] = __builtin_fmaf(-__builtin_fabsf(lo), 0x1.0p-20f, lo);
+        const float tf = __builtin_fmaf(__builtin_fabsf(hi), 0x1.0p-20f, hi);
+        // tf >= max(tn, 0) and not tn > bt (bt >= 0, or +inf)
+        hit[c] = __builtin_fminf(tf, bt) >= __builtin_fmaxf(tn[c], 0.0f);
     }
-    const f32x2 amin = { __builtin_fabsf(tmin.x), __builtin_fabsf(tmin.y) }, amax = { __builtin_fabsf(tmax.x), __builtin_fabsf(tmax.y) };
-    const f32x2 slack = { 0x1.0p-20f, 0x1.0p-20f };
-    tn = __builtin_elementwise_fma(-amin, slack, tmin);
-    const f32x2 tf = __builtin_elementwise_fma(amax, slack, tmax);
-    hit[0] = tf.x >= __builtin_fmaxf(tn.x, 0.0f);
-    hit[1] = tf.y >= __builtin_fmaxf(tn.y, 0.0f);
 }
 
 constexpr int BVH_STACK = 32;
@@ -310,12 +335,7 @@ RT_DEV Hit nearest_hit(SceneK S, double ox, double oy, double oz, double dx, dou
         scan_range<false>(S, 0, S->n_always, ox, oy, oz, dx, dy, dz, active, best, best_key, work);
     }
     if (S->n_nodes == 0) return best;
-    const float oxf = (float)ox, oyf = (float)oy, ozf = (float)oz;
-    const float pad = (__builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(oxf), __builtin_fabsf(oyf)), __builtin_fabsf(ozf)) + (float)S->box_scale) * 0x1.0p-21f;
-    const f32x2 ol[3] = { f32x2{ oxf + pad, oxf + pad }, f32x2{ oyf + pad, oyf + pad }, f32x2{ ozf + pad, ozf + pad } };
-    const f32x2 oh[3] = { f32x2{ oxf - pad, oxf - pad }, f32x2{ oyf - pad, oyf - pad }, f32x2{ ozf - pad, ozf - pad } };
-    const float idx = 1.0f / (float)dx, idy = 1.0f / (float)dy, idz = 1.0f / (float)dz;
-    const f32x2 id[3] = { f32x2{ idx, idx }, f32x2{ idy, idy }, f32x2{ idz, idz } };
+    const BoxRay br = box_ray(ox, oy, oz, dx, dy, dz, (float)S->box_scale);
     // "while-while" traversal: every lane walks inner nodes until it stands on a leaf (or has nothing left); only
     // then does the wave run the exact sphere tests, all leaf-holding lanes together.  Running them inside the
     // inner loop would charge every iteration of the wave with the two f64 sphere tests of whichever lane happens
@@ -351,18 +371,19 @@ RT_DEV Hit nearest_hit(SceneK S, double ox, double oy, double oz, double dx, dou
             if (node >= 0) {
                 work.node_visits += 1;
                 const BvhNode2 nd = S->nodes[node];
+                const int child0 = nd.child[0], child1 = nd.child[1];
                 f32x2 tn;
                 bool h[2];
-                box_intervals(nd, ol, oh, id, tn, h);
-                const bool h0 = h[0] && !(tn.x > bt), h1 = h[1] && !(tn.y > bt);
+                box_intervals(nd, br, bt, tn, h);
+                const bool h0 = h[0], h1 = h[1];
                 if (h0 && h1) {
                     const bool first0 = tn.x <= tn.y;
-                    node = first0 ? nd.child[0] : nd.child[1];
-                    stack[(2 * sp) * stack_stride] = first0 ? nd.child[1] : nd.child[0]; // depth is validated <= BVH_STACK on the host
+                    node = first0 ? child0 : child1;
+                    stack[(2 * sp) * stack_stride] = first0 ? child1 : child0; // depth is validated <= BVH_STACK on the host
                     stack[(2 * sp + 1) * stack_stride] = __float_as_int(first0 ? tn.y : tn.x);
                     ++sp;
                 } else if (h0 || h1) {
-                    node = h0 ? nd.child[0] : nd.child[1];
+                    node = h0 ? child0 : child1;
                 } else {
                     node = pop();
                 }

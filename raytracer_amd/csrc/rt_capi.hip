@@ -1566,8 +1566,7 @@ int32_t rt3d_scene_create(rt_ctx *ctx, const rt3d_scene_desc *d, rt3d_scene **ou
                 if (b.count > 0) continue;
                 for (int c = 0; c < 2; ++c) {
                     const rt3d::BvhNode &ch = bb.nodes[(size_t)b.left + (size_t)c];
-                    nodes[i].lox[c] = down(ch.lo[0]); nodes[i].loy[c] = down(ch.lo[1]); nodes[i].loz[c] = down(ch.lo[2]);
-                    nodes[i].hix[c] = up(ch.hi[0]); nodes[i].hiy[c] = up(ch.hi[1]); nodes[i].hiz[c] = up(ch.hi[2]);
+                    for (int a = 0; a < 3; ++a) { nodes[i].plane[2 * a][c] = down(ch.lo[a]); nodes[i].plane[2 * a + 1][c] = up(ch.hi[a]); }
                     for (int a = 0; a < 3; ++a) box_scale = std::max(box_scale, std::max(std::fabs(ch.lo[a]), std::fabs(ch.hi[a])));
                     // leaf ranges index the tree list; shift them past the always-tested spheres
                     nodes[i].child[c] = (ch.count > 0) ? ~(((ch.left + (int)always.size()) << 2) | ch.count) : b.left + c;
