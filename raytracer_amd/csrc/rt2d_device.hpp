@@ -122,9 +122,19 @@ RT_DEV bool segment_t(double ox, double oy, double rx, double ry, double ax, dou
     const double denom = rx * sy - ry * sx;
     if (__builtin_fabs(denom) < EPS64) return false;
     const double qx = ax - ox, qy = ay - oy;
+    // The reference divides twice (t and u) and asks 0 <= u <= 1.  u is only compared, and the rounded quotient
+    // compares like the exact one.  Signs agree (or un = 0): un / denom rounds to something <= 1 iff |un| <= |denom|
+    // (for |un| > |denom| the quotient is >= 1 + ulp(denom) / |denom| > 1 + 2^-53, past the midpoint above 1), and it
+    // is >= 0.  Signs differ: the quotient is negative unless it underflows to -0 (which compares >= 0), i.e. unless
+    // |un| / |denom| <= 2^-1075; scaling |un| by 2^1075 in two exact steps decides that (a larger |un| only overflows
+    // towards "no": |denom| < 2^82 for coordinates within 2^40).
+    const double un = qx * ry - qy * rx;
+    const double aun = __builtin_fabs(un), aden = __builtin_fabs(denom);
+    const bool same = (un < 0.0) == (denom < 0.0);
+    const bool u_ok = (same ? aun : (aun * 0x1.0p+1000) * 0x1.0p+75) <= aden;
+    if (!u_ok) return false;
     const double tt = (qx * sy - qy * sx) / denom;
-    const double u = (qx * ry - qy * rx) / denom;
-    if (tt >= 0.0 && u >= 0.0 && u <= 1.0) { t = tt; return true; }
+    if (tt >= 0.0) { t = tt; return true; }
     return false;
 }
 
@@ -236,6 +246,7 @@ RT_DEV uint32_t filter_segment_word(K_SegPair gp, const SegBounds &E, const Filt
     return ~acc | force;
 }
 
+template <bool WITH_SEGMENTS = true>
 RT_DEV uint32_t filter_word(int n_circ, K_CirclePair c32, K_SegPair segp, const SegBounds &E, int lo, int hi,
                             const FilterRay &f, uint32_t force)
 {
@@ -265,19 +276,21 @@ RT_DEV uint32_t filter_word(int n_circ, K_CirclePair c32, K_SegPair segp, const 
         rq = __builtin_elementwise_fma(-un, w, eq);  // < 0: u surely outside [0, 1]
         rp = __builtin_elementwise_fma(tn, den, ep); // < 0: t surely negative
     };
-    int s = s_lo;
-    K_SegPair gp = segp + ((s_lo - n_circ) >> 1);
+    if (WITH_SEGMENTS) {
+        int s = s_lo;
+        K_SegPair gp = segp + ((s_lo - n_circ) >> 1);
 #pragma unroll 2
-    for (; s + 2 <= hi; s += 2, ++gp) {
-        f32x2 rq, rp;
-        pair(gp, rq, rp);
-        acc = __builtin_amdgcn_alignbit(acc, __float_as_uint(rq.x) | __float_as_uint(rp.x), 31);
-        acc = __builtin_amdgcn_alignbit(acc, __float_as_uint(rq.y) | __float_as_uint(rp.y), 31);
-    }
-    if (s < hi) { // an odd segment count ends on half a pair: the other half is the padding element
-        f32x2 rq, rp;
-        pair(gp, rq, rp);
-        acc = __builtin_amdgcn_alignbit(acc, __float_as_uint(rq.x) | __float_as_uint(rp.x), 31);
+        for (; s + 2 <= hi; s += 2, ++gp) {
+            f32x2 rq, rp;
+            pair(gp, rq, rp);
+            acc = __builtin_amdgcn_alignbit(acc, __float_as_uint(rq.x) | __float_as_uint(rp.x), 31);
+            acc = __builtin_amdgcn_alignbit(acc, __float_as_uint(rq.y) | __float_as_uint(rp.y), 31);
+        }
+        if (s < hi) { // an odd segment count ends on half a pair: the other half is the padding element
+            f32x2 rq, rp;
+            pair(gp, rq, rp);
+            acc = __builtin_amdgcn_alignbit(acc, __float_as_uint(rq.x) | __float_as_uint(rp.x), 31);
+        }
     }
     // keep = not drop.  The ones this puts above the collected bits are shifted out below: exactly hi - lo bits
     // have been appended and the word is shifted up by 32 - (hi - lo).
@@ -308,13 +321,15 @@ struct CoopLds {
 // SEGW: the scene has words made of segments only, which then take their own straight-line filter (a kernel
 // compiled without it is ~1 % faster on scenes that have none).
 // SMALL: the scene has at most 32 slots (and at least one).
-template <bool SEGW = true, bool SMALL = false>
+// NOSEG: the scene has no segments at all; the kernel then carries neither their filter nor their exact test (the
+// stress scene is circles only, and the segment code it never runs still costs it registers: 21.65 -> 21.3 ms).
+template <bool SEGW = true, bool SMALL = false, bool NOSEG = false>
 RT_DEV Hit nearest_hit(SceneK S, double ox, double oy, double dx, double dy, bool active, CoopLds &L, Prof &prof)
 {
     S = fresh(S);
     // read once per call: inside the loops below the compiler would fetch them again for every word
     const int n_circ = S->n_circ;
-    const int P = n_circ + S->n_seg;
+    const int P = NOSEG ? n_circ : n_circ + S->n_seg;
     const K_CirclePair c32 = (K_CirclePair)S->c32;
     const CircleX *cex = S->cex;
     const SegX *sex = S->sex;
@@ -329,7 +344,7 @@ RT_DEV Hit nearest_hit(SceneK S, double ox, double oy, double dx, double dy, boo
         // The whole scene is one word: every lane's candidates sit in its own mask, a shared queue has nothing to
         // balance (the wave would walk max-over-lanes entries either way) and its LDS traffic and permutes are pure
         // cost.  Each lane walks its own bits and keeps the minimum of (key, pid) in registers.
-        uint32_t mw = filter_word(n_circ, c32, segp, E, 0, P, fr, force) & (0xFFFFFFFFu << (32 - P));
+        uint32_t mw = filter_word<!NOSEG>(n_circ, c32, segp, E, 0, P, fr, force) & (0xFFFFFFFFu << (32 - P));
         if (!active) mw = 0u;
         RT_STAMP(prof, 1);
 #ifdef RT_PROF
@@ -369,7 +384,7 @@ RT_DEV Hit nearest_hit(SceneK S, double ox, double oy, double dx, double dy, boo
             prof.t[11] += 1;
 #endif
         }
-        while (__any(ms != 0u)) {
+        while (!NOSEG && __any(ms != 0u)) {
             const int s = __clz((int)ms) & 31;
             const bool on = ms != 0u;
             ms &= ~(0x80000000u >> s);
@@ -404,7 +419,7 @@ RT_DEV Hit nearest_hit(SceneK S, double ox, double oy, double dx, double dy, boo
         uint32_t mw;
         if (hi - lo == 32 && hi <= n_circ) mw = filter_circle_word(c32 + (lo >> 1), fr, force);
         else if (SEGW && hi - lo == 32 && lo >= n_circ) mw = filter_segment_word(segp + ((lo - n_circ) >> 1), E, fr, force);
-        else mw = filter_word(n_circ, c32, segp, E, lo, hi, fr, force) & valid;
+        else mw = filter_word<!NOSEG>(n_circ, c32, segp, E, lo, hi, fr, force) & valid;
         if (!active) mw = 0u;
         RT_STAMP(prof, 1);
 #ifdef RT_PROF
@@ -448,7 +463,7 @@ RT_DEV Hit nearest_hit(SceneK S, double ox, double oy, double dx, double dy, boo
                 double t = 0.0;
                 int pid = 0;
                 if (on) {
-                    if (s < n_circ) {
+                    if (NOSEG || s < n_circ) {
                         const CircleX c = cex[s];
                         got = circle_t(rox, roy, rdx, rdy, c.cx, c.cy, c.r2, t);
                         pid = c.pid;

@@ -107,7 +107,7 @@ struct rt_ctx {
     void *scratch = nullptr; // this device's copy of the static scratch array (see STATIC_SCRATCH_BYTES)
     // resident workgroups per CU of the three render2d_kernel instantiations on this device, as the runtime computes
     // them from the kernel's registers and LDS (0 = not asked yet)
-    int per_cu2d[3] = { 0, 0, 0 };
+    int per_cu2d[5] = { 0, 0, 0, 0, 0 };
 };
 
 struct rt3d_scene; // per-scene occupancy of render3d_kernel lives in the scene: it depends on the tree's depth
@@ -706,12 +706,15 @@ int32_t launch_render2d(rt_ctx *ctx, const rt2d_scene *scene, const rt2d_render_
     // the kernel is compiled twice: with and without the filter for words made of segments only
     const int first_seg_word = (A.S.n_circ + 31) & ~31;
     const bool segw = first_seg_word + 32 <= A.S.n_circ + A.S.n_seg;
-    // ... and a third time for scenes of one word (at most 32 slots), which need no shared candidate queue
+    // ... a third time for scenes of one word (at most 32 slots), which need no shared candidate queue, and without
+    // any segment code for scenes that have none
     const int n_slots = A.S.n_circ + A.S.n_seg;
     const bool small = n_slots >= 1 && n_slots <= 32;
-    void (*const kernel)(const rtk::Render2dArgs) = small ? rtk::render2d_kernel<false, true>
-                                                   : segw ? rtk::render2d_kernel<true> : rtk::render2d_kernel<false>;
-    int &per_cu = ctx->per_cu2d[small ? 2 : (int)segw]; // per context: contexts live on different devices and threads
+    const bool noseg = scene->dev.n_seg == 0;
+    void (*const kernel)(const rtk::Render2dArgs) = small ? (noseg ? rtk::render2d_kernel<false, true, true> : rtk::render2d_kernel<false, true>)
+                                                   : segw ? rtk::render2d_kernel<true>
+                                                   : noseg ? rtk::render2d_kernel<false, false, true> : rtk::render2d_kernel<false>;
+    int &per_cu = ctx->per_cu2d[small ? (noseg ? 4 : 3) : segw ? 2 : (int)noseg]; // per context: contexts live on different devices and threads
     if (per_cu == 0) {
         int nb = 0;
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, rtk::BLOCK, 0));

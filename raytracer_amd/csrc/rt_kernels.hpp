@@ -96,8 +96,8 @@ struct PairSlab {
 // Units are small enough (about 1 k items) that the waves finish within a few percent of each other, and they are
 // numbered run-major so that the waves working at the same time are on different tiles.  A finished sample is added
 // to its pixel's bin in HBM with a hardware f32 atomic (the tile's 18 KB stay in L2 while a unit lasts).
-template <bool SEGW, bool SMALL = false>
-__global__ __launch_bounds__(BLOCK, 6) void render2d_kernel(const Render2dArgs A)
+template <bool SEGW, bool SMALL = false, bool NOSEG = false>
+__global__ __launch_bounds__(BLOCK, (SMALL || NOSEG) ? 7 : 6) void render2d_kernel(const Render2dArgs A)
 {
     __shared__ rt2d::CoopLds coop[SMALL ? 1 : BLOCK / 64];
     __shared__ ItemPool pools[BLOCK / 64];
@@ -244,7 +244,7 @@ __global__ __launch_bounds__(BLOCK, 6) void render2d_kernel(const Render2dArgs A
         prof.t[6] += (unsigned long long)__popcll(__ballot(run));
 #endif
         if (!have_hit) {
-            h = rt2d::nearest_hit<SEGW, SMALL>((rt2d::SceneK)&Ak->S, p.ox, p.oy, p.dx, p.dy, run, coop[SMALL ? 0 : (tid >> 6)], prof);
+            h = rt2d::nearest_hit<SEGW, SMALL, NOSEG>((rt2d::SceneK)&Ak->S, p.ox, p.oy, p.dx, p.dy, run, coop[SMALL ? 0 : (tid >> 6)], prof);
             if (run) ++nsearch;
             if (intake) {
                 slab.ox[lane] = p.ox; slab.oy[lane] = p.oy; slab.dx[lane] = p.dx; slab.dy[lane] = p.dy;
