@@ -155,7 +155,9 @@ def test_world_at_other_scales_and_far_from_the_origin(scale, offset, gpu_ctx, o
     scene.close()
 
 
-@pytest.mark.parametrize("n_circ,n_seg,w,h", [(40, 25, 24, 16), (7, 300, 19, 9)])
+# one case per compiled shape of the render kernel: circles and segments in mixed words / words of segments only /
+# one word with segments / one word of circles only / circles only
+@pytest.mark.parametrize("n_circ,n_seg,w,h", [(40, 25, 24, 16), (7, 300, 19, 9), (9, 14, 21, 13), (12, 0, 23, 11), (70, 0, 17, 12)])
 def test_random_world_render(n_circ, n_seg, w, h, gpu_ctx, oracle):
     rng = np.random.default_rng(77 + n_circ)
     world = random_world2d(rng, n_circ, n_seg)
