@@ -391,7 +391,7 @@ def main():
         else:
             merge = "XYZ projection + all-reduce + encode" if args.merge == "xyz" else "spectral all-reduce + resolve"
         if strong:
-            workload = (f"{work.describe()}; fixed job of {args.total_spp} spp split into {world_size} contiguous sample ranges "
+            workload = (f"{work.describe().replace(' spp/pass', ' spp/pass at most')}; fixed job of {args.total_spp} spp split into {world_size} contiguous sample ranges "
                         f"(BASELINE configs[4]); step = the whole job + {merge}")
         else:
             workload = f"{work.describe()}; job = {args.steps} steps + {merge}"
