@@ -1,0 +1,73 @@
+"""bench.py without a GPU: the roofline arithmetic and the link between the workloads it times and the committed
+rocprof summaries it replays its executed-instruction fields from."""
+import ast
+import json
+import os
+import re
+
+import bench
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def default_tags():
+    """Tags of the workloads the default run times, read from the Work2D / Work3D calls in bench.py's source."""
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    tags = ["complex_world_1920x1080_s64_l2"]  # the headline: the argparse defaults
+    for m in re.finditer(r'Work2D\(rt, torch, ctx, "(\w+)", (\d+), (\d+), (\d+), (\d+), \d+\)', src):
+        name, w, h, spp, ls = m.groups()
+        tags.append(f"{name}_{w}x{h}_s{spp}_l{ls}")
+    for m in re.finditer(r"Work3D\(rt, torch, ctx, (\d+), (\d+), (\d+), \d+, (True|False)\)", src):
+        w, h, spp, bvh = m.groups()
+        tags.append(f"3d_{'bvh' if bvh == 'True' else 'linear'}_{w}x{h}_s{spp}")
+    return tags
+
+
+def test_argparse_defaults_are_the_headline():
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    tree = ast.parse(src)
+    defaults = {}
+    for node in ast.walk(tree):
+        if isinstance(node, ast.Call) and getattr(node.func, "attr", "") == "add_argument" and node.args:
+            flag = node.args[0].value
+            for kw in node.keywords:
+                if kw.arg == "default" and isinstance(kw.value, ast.Constant):
+                    defaults[flag] = kw.value.value
+    assert (defaults["--scene"], defaults["--width"], defaults["--height"]) == ("complex_world", 1920, 1080)
+    assert (defaults["--spp"], defaults["--lambda-samples"], defaults["--depth"]) == (64, 2, 10)
+    assert defaults["--gpus"] == 1 and defaults["--mode"] == "weak"
+
+
+def test_every_default_workload_has_committed_counters():
+    tags = default_tags()
+    assert len(tags) == 7 and len(set(tags)) == 7
+    for tag in tags:
+        prof = bench.profile_counters(tag)
+        assert prof is not None, f"no profiles/r*/pmc_{tag}.json"
+        assert os.path.exists(os.path.join(ROOT, prof["source"]))
+        assert 0.3 < prof["valu_issue_frac"] < 1.3
+        assert prof["hbm_bytes_per_launch"] > 0 and prof["valu_insts_per_launch"] > 0
+        stats = [f for f in os.listdir(os.path.dirname(os.path.join(ROOT, prof["source"]))) if f == f"kernel_stats_{tag}.csv"]
+        assert stats, f"no kernel_stats_{tag}.csv beside {prof['source']}"
+    assert bench.profile_counters("no_such_workload_1x1_s1_l1") is None
+
+
+def test_roofline_arithmetic():
+    st = {"launches": 5, "kernel_ms": 100.0, "rays": 5 * 575e6, "searches": 5 * 440e6, "bvh_node_visits": 5 * 3.1e9,
+          "sphere_tests": 5 * 1.7e9}
+    r = bench.roofline("2d", st, "render2d_kernel", 200, 2.0e9, "complex_world_1920x1080_s64_l2")
+    flop = 575e6 * (15 * 200 + 60)
+    assert abs(r["achieved"] - flop / 20e-3 / 1e12) < 1e-9
+    assert r["peak"] == 157.3 and abs(r["frac"] - r["achieved"] / 157.3) < 1e-12 and r["frac"] < 1.0
+    assert r["kernel_ms"] == 20.0 and r["bound"] == "valu" and r["unit"] == "TFLOP/s"
+    ex = r["executed_work"]
+    assert abs(ex["achieved"] - (440e6 * 15 * 200 + 575e6 * 60) / 20e-3 / 1e12) < 1e-9 and ex["peak"] == 78.6
+    assert r["traffic"] == r["executed"]["hbm_bytes_per_launch"] and r["executed"]["source"].startswith("profiles/")
+    r3 = bench.roofline("3d_linear", st, "render3d_kernel<false>", 218, 1.0e9, "3d_linear_1920x1080_s128")
+    assert abs(r3["achieved"] - 575e6 * (23 * 218 + 60) / 20e-3 / 1e12) < 1e-9 and "executed_work" not in r3
+    rb = bench.roofline("3d_bvh", st, "render3d_kernel<true>", 218, 1.0e9, "3d_bvh_1920x1080_s128")
+    assert abs(rb["achieved"] - (3.1e9 * 2 * 30 + 1.7e9 * 23 + 575e6 * 60) / 20e-3 / 1e12) < 1e-9
+    # a workload nobody profiled still gets its measured fields
+    rn = bench.roofline("2d", st, "render2d_kernel", 11, 1.0e9, "some_world_10x10_s1_l1")
+    assert rn["traffic"] is None and "executed" not in rn
+    json.dumps([r, r3, rb, rn])
