@@ -287,12 +287,17 @@ RT_DEV BoxRay box_ray(double ox, double oy, double oz, double dx, double dy, dou
 
 RT_DEV void box_intervals(const BvhNode2 &nd, const BoxRay &r, float bt, f32x2 &tn, bool hit[2])
 {
-    f32x2 t1[3], t2[3];
+    // plain f32 steps, not packed ones: a packed operand wants the ray's constants duplicated into register pairs (18
+    // registers instead of 9, which this kernel does not have), and two v_fma_f32 issue in about the time of one
+    // v_pk_fma_f32
+    float t1[3][2], t2[3][2];
 #pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        t1[a] = __builtin_elementwise_fma(nd.plane[2 * a], f32x2{ r.idf[a], r.idf[a] }, f32x2{ r.c_lo[a], r.c_lo[a] });
-        t2[a] = __builtin_elementwise_fma(nd.plane[2 * a + 1], f32x2{ r.idf[a], r.idf[a] }, f32x2{ r.c_hi[a], r.c_hi[a] });
-    }
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            t1[a][c] = __builtin_fmaf(nd.plane[2 * a][c], r.idf[a], r.c_lo[a]);
+            t2[a][c] = __builtin_fmaf(nd.plane[2 * a + 1][c], r.idf[a], r.c_hi[a]);
+        }
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
         const float lo = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(t1[0][c], t2[0][c]), __builtin_fminf(t1[1][c], t2[1][c])), __builtin_fminf(t1[2][c], t2[2][c]));
