@@ -1,0 +1,58 @@
+"""Image sizes, sample counts and depths at the edges of what the render entries take: one pixel, fewer pixels than a
+tile, one sample, 95 lambda-samples, depth 0 and 1, an 8K image.  Counts are exact against the CPU checker, sums to f32
+accumulation tolerance."""
+import numpy as np
+import pytest
+
+import raytracer_amd as rt
+from raytracer_amd.api import params2d, params3d
+
+pytestmark = pytest.mark.gpu
+
+SIZES = [(1, 1, 1, 1, 1), (1, 1, 3, 95, 10), (17, 3, 1, 7, 2), (65, 9, 2, 1, 10), (8, 8, 5, 33, 0), (3, 129, 64, 2, 1)]
+
+
+@pytest.mark.parametrize("name", ["complex_world", "cornell_box", "sample_world"])
+def test_small_and_ragged_2d_renders(name, gpu_ctx, oracle):
+    world = rt.World2D(name, seed=1)
+    scene = rt.Scene2D(gpu_ctx, world)
+    for (w, h, spp, ls, depth) in SIZES:
+        p = params2d(w, h, spp, ls, depth, seed=5)
+        gpu_ctx.reset_stats()
+        rgb, weight, spec = scene.global_render(p, want_spectrum=True)
+        st = gpu_ctx.stats()
+        orgb, ow, ospec, orays = oracle.render2d(world, p, threads=4, want_spectrum=True)
+        assert st["rays"] == orays, (w, h, spp, ls, depth)
+        assert st["samples"] == w * h * spp * ls
+        assert np.allclose(spec, ospec, rtol=1e-5, atol=1e-7), (w, h, spp, ls, depth)
+        assert np.array_equal(weight, ow)
+    scene.close()
+
+
+def test_8k_image_few_samples(gpu_ctx):
+    import torch
+    scene = rt.Scene2D(gpu_ctx, rt.World2D("complex_world", seed=1))
+    w, h = 7680, 4320
+    buf = torch.zeros(w * h * rt.NBINS, dtype=torch.float32, device="cuda")
+    gpu_ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    gpu_ctx.reset_stats()
+    scene.accumulate(params2d(w, h, 2, 1, 10, seed=0), buf.data_ptr())
+    gpu_ctx.synchronize()
+    st = gpu_ctx.stats()
+    gpu_ctx.set_stream(None)
+    assert st["samples"] == w * h * 2 and st["rays"] >= st["samples"] and st["searches"] == st["rays"]
+    # every pixel traced its samples: the emissive circles and the white sky-less scene leave most pixels lit
+    lit = (buf.view(h * w, rt.NBINS).sum(1) > 0).float().mean().item()
+    assert 0.2 < lit <= 1.0
+    scene.close()
+
+
+@pytest.mark.parametrize("use_bvh", [False, True])
+def test_small_3d_renders(use_bvh, gpu_ctx, oracle):
+    s = rt.Standalone3D(7, 5, use_bvh=use_bvh)
+    scene = rt.Scene3D(gpu_ctx, s)
+    for (spp, depth) in [(1, 1), (3, 0), (2, 50)]:
+        img = scene.render(params3d(spp, depth, seed=2))
+        oimg, _ = oracle.render3d(s, params3d(spp, depth, seed=2))
+        assert np.allclose(img, oimg, rtol=1e-5, atol=1e-6), (spp, depth)
+    scene.close()
