@@ -107,6 +107,12 @@ def roofline(kind, st, kernel, n_prims, hbm_bytes_per_launch, tag):
         out["executed_work"] = {"achieved": executed / sec / 1e12, "peak": F64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
                                 "frac": executed / sec / 1e12 / F64_VECTOR_PEAK_TFLOPS,
                                 "model": f"searches x 15 x {n_prims} + rays x 60 FLOP"}
+    if kind == "3d_bvh":
+        # for comparison with the linear-scan line only: the work the reference's scan does for the same rays, over
+        # this kernel's time.  The tree skips most of it, so this is no utilisation and can exceed any peak.
+        scan = rays * (FLOP_PER_SPHERE_TEST * n_prims + FLOP_PER_SHADE)
+        out["reference_scan_equivalent"] = {"achieved": scan / sec / 1e12, "unit": "TFLOP/s",
+                                            "model": f"rays x (23 x {n_prims} + 60) FLOP, the linear scan's work for the same rays; not a fraction of a peak"}
     prof = profile_counters(tag)
     if prof:
         out["traffic"] = prof.get("hbm_bytes_per_launch")

@@ -67,6 +67,7 @@ def test_roofline_arithmetic():
     assert abs(r3["achieved"] - 575e6 * (23 * 218 + 60) / 20e-3 / 1e12) < 1e-9 and "executed_work" not in r3
     rb = bench.roofline("3d_bvh", st, "render3d_kernel<true>", 218, 1.0e9, "3d_bvh_1920x1080_s128")
     assert abs(rb["achieved"] - (3.1e9 * 2 * 30 + 1.7e9 * 23 + 575e6 * 60) / 20e-3 / 1e12) < 1e-9
+    assert rb["frac"] < 1.0 and abs(rb["reference_scan_equivalent"]["achieved"] - r3["achieved"]) < 1e-9
     # a workload nobody profiled still gets its measured fields
     rn = bench.roofline("2d", st, "render2d_kernel", 11, 1.0e9, "some_world_10x10_s1_l1")
     assert rn["traffic"] is None and "executed" not in rn
