@@ -110,7 +110,6 @@ __global__ __launch_bounds__(BLOCK, (SMALL || NOSEG) ? 7 : 6) void render2d_kern
 
     const int n_lambda = Ak->lambda_samples;
     const int total = TILE2D_PIXELS * Ak->spp; // pairs of a tile
-    const float inv_scale_l = (float)n_lambda;
 
     rt2d::Path p;
     p.ox = p.oy = p.dx = p.dy = 0.0;
@@ -120,8 +119,10 @@ __global__ __launch_bounds__(BLOCK, (SMALL || NOSEG) ? 7 : 6) void render2d_kern
     int tile = 0, cursor = 0, cursor_end = 0, tx = 0, ty = 0; // wave-uniform; the cursor counts pairs
     int pool_pos = 0, pool_items = 0;                         // wave-uniform
     int set_lambda = n_lambda; // wave-uniform: next lambda-sample of the pair set in the slab to take in (n_lambda: none left)
-    ItemPool &pool = pools[tid >> 6];
-    PairSlab &slab = Ak->pairs[blockIdx.x * (BLOCK / 64) + (tid >> 6)];
+    // the wave's index as a scalar: the addresses of its pool and slab rows are then scalar base + lane offset
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    ItemPool &pool = pools[wave];
+    PairSlab &slab = Ak->pairs[blockIdx.x * (BLOCK / 64) + wave];
     uint32_t orow = 0;     // row of `out` this lane's path adds to
     uint32_t set_bins = 0; // wavelength bins of four consecutive lambda-samples of this lane's pair of the set, one byte each
     uint32_t nrays = 0, nsearch = 0;
@@ -269,7 +270,7 @@ __global__ __launch_bounds__(BLOCK, (SMALL || NOSEG) ? 7 : 6) void render2d_kern
                 if (value != 0.0f) {
                     // per-sample term of `spectrum_spp / lambda_samples * 95` (librt2d_reverse.rs:104-105)
                     const float v = p.thr * value;
-                    const float c = v / inv_scale_l * (float)NBINS;
+                    const float c = v / (float)n_lambda * (float)NBINS;
                     unsafeAtomicAdd(Ak->out + (int64_t)orow * NBINS + p.li, c);
                 }
                 act = false;
