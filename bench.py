@@ -165,7 +165,7 @@ class Work2D:
         self.buf.zero_()
 
     def render_pass(self, first_sample, spp=None):
-        self.scene.accumulate(self.params2d(self.W, self.H, spp or self.spp, self.ls, self.depth, seed=0, sample_offset=first_sample),
+        self.scene.accumulate(self.params2d(self.W, self.H, self.spp if spp is None else spp, self.ls, self.depth, seed=0, sample_offset=first_sample),
                               self.buf.data_ptr())
 
     def finish(self, total_spp, reduce_sum):
@@ -212,7 +212,7 @@ class Work3D:
         self.buf.zero_()
 
     def render_pass(self, first_sample, spp=None):
-        self.scene.accumulate(self.params3d(spp or self.spp, self.depth, seed=0, sample_offset=first_sample), self.buf.data_ptr())
+        self.scene.accumulate(self.params3d(self.spp if spp is None else spp, self.depth, seed=0, sample_offset=first_sample), self.buf.data_ptr())
 
     def finish(self, total_spp, reduce_sum):
         if reduce_sum is not None:
@@ -245,6 +245,52 @@ def time_config(torch, ctx, work, steps, warmup):
             "roofline": roofline(work.kind, st, work.kernel, work.n_prims, work.hbm_bytes_per_launch, work.tag)}
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as child processes of this one (same
+    interpreter, same arguments, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set as torch.distributed.run sets them),
+    wait for all of them and return the first non-zero exit code.  This parent never imports torch and never touches
+    HIP, and nothing is exec'ed from a process that has: the children are ordinary subprocesses.  Rank 0's one JSON
+    line goes to this process's stdout; the other ranks print nothing there."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(os.environ.get("MASTER_PORT", port)))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL needs on this driver
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    try:
+        # a rank that dies leaves the others waiting in a collective: once one has failed, the rest get a grace
+        # period and are then terminated
+        pending = list(procs)
+        deadline = None
+        while pending:
+            for p in list(pending):
+                code = p.poll()
+                if code is not None:
+                    pending.remove(p)
+                    if code != 0 and rc == 0:
+                        rc = code if code > 0 else 1
+                        deadline = time.monotonic() + 30.0
+            if deadline is not None and time.monotonic() > deadline:
+                break
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                p.kill()
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -273,6 +319,10 @@ def main():
         import faulthandler
         faulthandler.dump_traceback_later(float(os.environ["RT_BENCH_WATCHDOG"]), exit=True)
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # invoked plainly (no launcher): this process becomes the launcher, before anything here touches torch or HIP
+        raise SystemExit(spawn_ranks(args.gpus))
+
     import torch
     import torch.distributed as dist
 
@@ -280,7 +330,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world_size != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world_size}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world_size}: give both the same number of ranks")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU implementation")
     # RT_BENCH_BACKEND=gloo rehearses the N > 1 code path on a box with fewer GPUs than ranks (ranks then share devices)
@@ -344,7 +394,12 @@ def main():
             for _ in range(n_jobs):
                 work.clear()
                 job()
-        warm = lambda: (work.render_pass(lo, min(work.spp, hi - lo)), work.finish(args.total_spp, merge_fn))  # noqa: E731
+
+        def warm():
+            # a rank whose part of the job is empty (more ranks than samples) renders nothing but still joins the merge
+            if hi > lo:
+                work.render_pass(lo, min(work.spp, hi - lo))
+            work.finish(args.total_spp, merge_fn)
     else:
         def run(n_steps):
             for i in range(n_steps):
@@ -403,7 +458,7 @@ def main():
             workload = f"{work.describe()}; job = {args.steps} steps + {merge}"
         out = {
             "metric": "Mrays/s", "value": total_rays / dt / 1e6, "unit": "Mrays/s",
-            "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": world_size, "ranks": dist.get_world_size() if world_size > 1 else 1, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if strong else "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": workload, "parallelism": f"sample-batch x{world_size}",

@@ -72,3 +72,30 @@ def test_roofline_arithmetic():
     rn = bench.roofline("2d", st, "render2d_kernel", 11, 1.0e9, "some_world_10x10_s1_l1")
     assert rn["traffic"] is None and "executed" not in rn
     json.dumps([r, r3, rb, rn])
+
+
+def test_plain_multi_gpu_invocation_becomes_the_launcher(tmp_path, monkeypatch):
+    """`python bench.py --gpus N` without WORLD_SIZE starts N child ranks (no torch, no HIP in the parent) and
+    hands back the first failing rank's exit code.  Here the children are a stand-in script."""
+    import subprocess
+    import sys
+    script = tmp_path / "fake_bench.py"
+    script.write_text("import os, sys\n"
+                      "r = int(os.environ['RANK']); assert os.environ['WORLD_SIZE'] == '3' and os.environ['LOCAL_RANK'] == str(r)\n"
+                      "assert os.environ['MASTER_ADDR'] == '127.0.0.1' and int(os.environ['MASTER_PORT']) > 0\n"
+                      "open(os.path.join(os.path.dirname(__file__), f'rank{r}'), 'w').write(' '.join(sys.argv[1:]))\n"
+                      "sys.exit(int(os.environ.get('FAIL_RANK', '-1')) == r and 7 or 0)\n")
+    monkeypatch.setattr(bench, "__file__", str(script))
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "3", "--steps", "2"])
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "FAIL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    assert bench.spawn_ranks(3) == 0
+    assert sorted(p.name for p in tmp_path.glob("rank*")) == ["rank0", "rank1", "rank2"]
+    assert (tmp_path / "rank1").read_text() == "--gpus 3 --steps 2"
+    monkeypatch.setenv("FAIL_RANK", "1")
+    assert bench.spawn_ranks(3) == 7
+    # and main() takes that road before importing torch
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert src.index("spawn_ranks(args.gpus)") < src.index("    import torch\n")
+    assert "launch with torch.distributed.run" not in src
+    del subprocess
