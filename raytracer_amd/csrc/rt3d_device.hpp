@@ -28,7 +28,7 @@ struct BvhNode {
 
 // Traversal node, 64 B, one per inner build node: the boxes of BOTH children in f32, component c of every field
 // belonging to child c (so one packed f32 instruction works on both boxes), and what each child is.
-// child >= 0: index of an inner node; child < 0: a leaf, ~child = first slot << 2 | count (count <= 2).
+// child >= 0: index of an inner node; child < 0: a leaf, ~child = first slot << 3 | count (count <= LEAF_MAX).
 // Slots are BVH leaf order; `sid` maps a slot back to the caller's sphere index.  Boxes are rounded
 // outward to f32 from boxes already padded by 1e-7 x scene scale; the traversal adds a per-ray pad and a
 // relative slack (see box_intervals), so a sphere hit at distance t always lies inside [tn, tf] of every
@@ -39,6 +39,18 @@ struct BvhNode2 {
     int32_t child[2];
     int32_t pad_[2];
 };
+
+// Most spheres a leaf holds.  A leaf is not a box test followed by exact tests: the walk runs the f32 sphere filter
+// (leaf_filter) on all of a leaf's spheres at once, which costs less per sphere than a box test and passes far fewer
+// misses on to the exact f64 test than the sphere's box would.
+#ifndef RT_LEAF_MAX
+#define RT_LEAF_MAX 4
+#endif
+constexpr int LEAF_MAX = RT_LEAF_MAX;
+static_assert(LEAF_MAX >= 1 && LEAF_MAX <= 7, "the count shares three bits of a child reference");
+
+// One sphere as a leaf's filter reads it (one 16-byte load per lane), in slot order; same values as SpherePair's.
+struct SphereF32 { float vx, vy, vz, e; };
 
 // Two spheres as the f32 filter reads them, each field holding the value of both (one scalar load and one address
 // per pair: with four separate arrays the loop's scalar side weighs as much as its vector side).
@@ -55,6 +67,8 @@ struct SceneDev {
     // and e = |v|^2 - r^2 (1 + 2^-22) rounded down (-inf for a sphere the frame does not hold: always a candidate;
     // +inf in an odd count's spare half: never one)
     const SpherePair *f32p;
+    // BVH mode: the same per slot, followed by LEAF_MAX spare records (a leaf always reads LEAF_MAX of them)
+    const SphereF32 *f32s;
     double filt_m[3], filt_B;
     double box_scale; // largest |coordinate| of a tree box
     double pos[3], p00[3], du[3], dv[3];
@@ -156,14 +170,14 @@ RT_DEV uint32_t filter_word(SceneK S, int lo, int hi, double ox, double oy, doub
 //   g >= 0   whenever the reference's delta >= 0.
 // A ray near the scene gets a thin pad; one that starts far away (a bounce off the ground plane's far side)
 // gets a wide one and more candidates, but never the f64 loop.
-struct FilterRay3 {
-    f32x2 dx, dy, dz;       // direction, each duplicated into both halves
-    f32x2 ndu;              // -(d . u)
-    f32x2 m2ux, m2uy, m2uz; // -2 u
-    f32x2 k;                // |u|^2 - pad, rounded down
+struct FilterTerms {
+    float dx, dy, dz;       // direction
+    float ndu;              // -(d . u)
+    float m2ux, m2uy, m2uz; // -2 u
+    float k;                // |u|^2 - pad, rounded down
 };
 
-RT_DEV FilterRay3 filter_ray(SceneK S, double ox, double oy, double oz, double dx, double dy, double dz, bool &in_range)
+RT_DEV FilterTerms filter_terms(SceneK S, double ox, double oy, double oz, double dx, double dy, double dz, bool &in_range)
 {
     const double ux = ox - S->filt_m[0], uy = oy - S->filt_m[1], uz = oz - S->filt_m[2];
     in_range = __builtin_fabs(((dx * dx + dy * dy) + dz * dz) - 1.0) <= 0x1.0p-40;
@@ -171,15 +185,57 @@ RT_DEV FilterRay3 filter_ray(SceneK S, double ox, double oy, double oz, double d
     const double kd = ((ux * ux + uy * uy) + uz * uz) - reach * reach * (128.0 * 0x1.0p-24);
     float kf = (float)kd;
     if ((double)kf > kd) kf -= __builtin_fmaxf(__builtin_fabsf(kf) * 0x1.0p-23f, 0x1.0p-126f); // at least one ulp down
-    const float fx = (float)dx, fy = (float)dy, fz = (float)dz;
-    const float ndu = -(float)((dx * ux + dy * uy) + dz * uz);
-    const float ax = -2.0f * (float)ux, ay = -2.0f * (float)uy, az = -2.0f * (float)uz;
-    FilterRay3 f;
-    f.dx = f32x2{ fx, fx }; f.dy = f32x2{ fy, fy }; f.dz = f32x2{ fz, fz };
-    f.ndu = f32x2{ ndu, ndu };
-    f.m2ux = f32x2{ ax, ax }; f.m2uy = f32x2{ ay, ay }; f.m2uz = f32x2{ az, az };
-    f.k = f32x2{ kf, kf };
+    FilterTerms f;
+    f.dx = (float)dx; f.dy = (float)dy; f.dz = (float)dz;
+    f.ndu = -(float)((dx * ux + dy * uy) + dz * uz);
+    f.m2ux = -2.0f * (float)ux; f.m2uy = -2.0f * (float)uy; f.m2uz = -2.0f * (float)uz;
+    f.k = kf;
     return f;
+}
+
+struct FilterRay3 {
+    f32x2 dx, dy, dz;       // the terms above, each duplicated into both halves
+    f32x2 ndu;
+    f32x2 m2ux, m2uy, m2uz;
+    f32x2 k;
+};
+
+RT_DEV FilterRay3 filter_ray(SceneK S, double ox, double oy, double oz, double dx, double dy, double dz, bool &in_range)
+{
+    const FilterTerms t = filter_terms(S, ox, oy, oz, dx, dy, dz, in_range);
+    FilterRay3 f;
+    f.dx = f32x2{ t.dx, t.dx }; f.dy = f32x2{ t.dy, t.dy }; f.dz = f32x2{ t.dz, t.dz };
+    f.ndu = f32x2{ t.ndu, t.ndu };
+    f.m2ux = f32x2{ t.m2ux, t.m2ux }; f.m2uy = f32x2{ t.m2uy, t.m2uy }; f.m2uz = f32x2{ t.m2uz, t.m2uz };
+    f.k = f32x2{ t.k, t.k };
+    return f;
+}
+
+// The same filter for the LEAF_MAX spheres of one BVH leaf, each lane on its own leaf: plain f32 steps on per-lane
+// 16-byte records (8 operations and one v_alignbit per sphere; a box test is 18 and passes about twice the misses).
+// A ray whose direction is not a unit vector carries k = -inf, which makes every sphere a candidate (c = -inf,
+// g = +inf; every other operand is finite, so no NaN arises for a real sphere).  Returns the candidate bits,
+// bit j = sphere first + j.
+RT_DEV FilterTerms leaf_ray(SceneK S, double ox, double oy, double oz, double dx, double dy, double dz)
+{
+    bool in_range;
+    FilterTerms t = filter_terms(S, ox, oy, oz, dx, dy, dz, in_range);
+    if (!in_range) t.k = -__builtin_inff();
+    return t;
+}
+
+RT_DEV uint32_t leaf_filter(const SphereF32 *q, int cnt, const FilterTerms &f)
+{
+    uint32_t acc = 0; // collects DROP bits (the sign of g), the last sphere first
+#pragma unroll
+    for (int j = LEAF_MAX - 1; j >= 0; --j) {
+        const SphereF32 s = q[j];
+        const float h = __builtin_fmaf(f.dx, s.vx, __builtin_fmaf(f.dy, s.vy, __builtin_fmaf(f.dz, s.vz, f.ndu)));
+        const float c = __builtin_fmaf(f.m2ux, s.vx, __builtin_fmaf(f.m2uy, s.vy, __builtin_fmaf(f.m2uz, s.vz, s.e + f.k)));
+        const float g = __builtin_fmaf(h, h, -c);
+        acc = __builtin_amdgcn_alignbit(acc, __float_as_uint(g), 31);
+    }
+    return ~acc & ((1u << cnt) - 1u);
 }
 
 RT_DEV uint32_t filter_word32(SceneK S, int lo, int hi, const FilterRay3 &f)
@@ -309,58 +365,79 @@ RT_DEV void box_intervals(const BvhNode2 &nd, const BoxRay &r, float bt, f32x2 &
     }
 }
 
-constexpr int BVH_STACK = 32;
-
-// `stack` points at this lane's column of an LDS array laid out [level][2][lane]: child index and the
-// lower end of its interval (float bits), so that a popped subtree can be dropped without a visit when a
-// nearer hit has been found since it was pushed.
-// BVH = false: the reference's linear scan over every sphere (with the f32 filter ahead of the exact tests).
-// BVH = true: the spheres kept out of the tree, then the tree.  A kernel is compiled for each so that neither
-// carries the other's registers.
-template <bool BVH>
-RT_DEV Hit nearest_hit(SceneK S, double ox, double oy, double oz, double dx, double dy, double dz,
-                       bool active, int32_t *stack, int stack_stride, Work &work)
+RT_DEV Hit no_hit()
 {
-    S = fresh(S);
     Hit best;
     best.t = 0.0;
     best.slot = -1;
     best.sid = 0x7fffffff;
-    int64_t best_key = 0x7fffffffffffffffLL;
-    if (!BVH) {
-        scan_range<true>(S, 0, S->n, ox, oy, oz, dx, dy, dz, active, best, best_key, work);
-        return best;
-    }
-    // the spheres kept out of the tree are one or two (the ground): the exact test on every lane costs less than the
-    // filter pass over eight mostly empty words and its mask bookkeeping (standalone scene: 31.2 -> 33.5 Grays/s)
+    return best;
+}
+
+// Key of a hit record in f64::total_cmp order (rt.rs:224); the largest key while there is none.
+RT_DEV int64_t hit_key(const Hit &h) { return h.slot >= 0 ? total_key(h.t) : 0x7fffffffffffffffLL; }
+
+// A hit as an f32 at or above it: a box whose interval starts beyond THAT starts beyond the hit (equal t may
+// still win on index, so only strictly later boxes are dropped); +inf while there is no hit.
+RT_DEV float hit_bound(const Hit &best)
+{
+    if (best.slot < 0) return __builtin_inff();
+    float f = (float)best.t;
+    if ((double)f < best.t) f = __uint_as_float(__float_as_uint(f) + 1u); // best.t >= 0 here: next float up
+    return f;
+}
+
+// The spheres kept out of the tree (BVH mode): exact tests on every ray.  They are one or two (the ground): the
+// exact test on every lane costs less than the filter pass over eight mostly empty words and its mask bookkeeping
+// (standalone scene: 31.2 -> 33.5 Grays/s).
+RT_DEV void always_hits(SceneK S, double ox, double oy, double oz, double dx, double dy, double dz, bool active,
+                        Hit &best, int64_t &best_key, Work &work)
+{
     if (S->n_always <= 4) {
         if (active)
             for (int s = 0; s < S->n_always; ++s) consider(S, s, ox, oy, oz, dx, dy, dz, best, best_key, work);
     } else {
         scan_range<false>(S, 0, S->n_always, ox, oy, oz, dx, dy, dz, active, best, best_key, work);
     }
-    if (S->n_nodes == 0) return best;
-    const BoxRay br = box_ray(ox, oy, oz, dx, dy, dz, (float)S->box_scale);
+}
+
+// Does the ray reach either child box of the root before the hit it already has?  (The root's own visit, with the
+// node read as scalar operands: it is the same for every lane.)  A ray that does not is finished with the tree.
+typedef const BvhNode2 __attribute__((address_space(4))) *K_BvhNode2;
+RT_DEV bool enters_tree(SceneK S, const BoxRay &br, const Hit &best, Work &work)
+{
+    work.node_visits += 1; // counted again when the walk starts at the root: both are executed
+    const K_BvhNode2 root = (K_BvhNode2)S->nodes;
+    BvhNode2 nd;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) nd.plane[i] = root->plane[i];
+    f32x2 tn;
+    bool h[2];
+    box_intervals(nd, br, hit_bound(best), tn, h);
+    return h[0] || h[1];
+}
+
+constexpr int BVH_STACK = 32;
+
+// The tree walk, from the root, for a ray that may already hold a hit (`best`, `best_key`).
+// `stack` points at this lane's column of an LDS array laid out [level][2][lane]: child index and the
+// lower end of its interval (float bits), so that a popped subtree can be dropped without a visit when a
+// nearer hit has been found since it was pushed.
+RT_DEV void walk_tree(SceneK S, double ox, double oy, double oz, double dx, double dy, double dz, bool active,
+                      const BoxRay &br, int32_t *stack, int stack_stride, Hit &best, int64_t &best_key, Work &work, Prof &prof)
+{
+    (void)prof;
+    const FilterTerms lr = leaf_ray(S, ox, oy, oz, dx, dy, dz);
     // "while-while" traversal: every lane walks inner nodes until it stands on a leaf (or has nothing left); only
-    // then does the wave run the exact sphere tests, all leaf-holding lanes together.  Running them inside the
-    // inner loop would charge every iteration of the wave with the two f64 sphere tests of whichever lane happens
-    // to be at a leaf (27.5 -> 29.7 Grays/s on the standalone scene; leaving the inner loop early, once fewer than
+    // then does the wave run the leaves' sphere filter and exact tests, all leaf-holding lanes together.  Running
+    // them inside the inner loop would charge every iteration of the wave with the f64 sphere tests of whichever lane
+    // happens to be at a leaf (27.5 -> 29.7 Grays/s on the standalone scene; leaving the inner loop early, once fewer than
     // 8..32 lanes still walk, was slower: 26.8..27.7).  A child reference is an inner node (>= 0) or a leaf
     // (< 0, see BvhNode2); NONE = finished.
     constexpr int NONE = (int)0x80000000;
     int sp = 0;
     int node = active ? 0 : NONE;
-    // the best hit so far as an f32 at or above it: a box whose interval starts beyond THAT starts beyond the hit
-    // (equal t may still win on index, so only strictly later boxes are dropped); +inf while there is no hit
-    float bt = __builtin_inff();
-    auto note_best = [&]() {
-        if (best.slot >= 0) {
-            float f = (float)best.t;
-            if ((double)f < best.t) f = __uint_as_float(__float_as_uint(f) + 1u); // best.t >= 0 here: next float up
-            bt = f;
-        }
-    };
-    note_best();
+    float bt = hit_bound(best);
     // next subtree from the stack whose interval still starts before the best hit
     auto pop = [&]() {
         while (sp > 0) {
@@ -371,8 +448,12 @@ RT_DEV Hit nearest_hit(SceneK S, double ox, double oy, double oz, double dx, dou
         }
         return NONE;
     };
+    RT_STAMP(prof, 1);
     while (__any(node != NONE)) {
         while (__any(node >= 0)) {
+#ifdef RT_PROF
+            prof.t[7] += 1;
+#endif
             if (node >= 0) {
                 work.node_visits += 1;
                 const BvhNode2 nd = S->nodes[node];
@@ -394,14 +475,48 @@ RT_DEV Hit nearest_hit(SceneK S, double ox, double oy, double oz, double dx, dou
                 }
             }
         }
-        if (node != NONE) { // a leaf: <= 2 spheres
+        RT_STAMP(prof, 2);
+#ifdef RT_PROF
+        prof.t[8] += 1;
+        prof.t[10] += (unsigned long long)__popcll(__ballot(node != NONE));
+#endif
+        if (node != NONE) { // a leaf: the f32 filter on its spheres, the exact test on what it leaves
             const int enc = ~node;
-            const int first = enc >> 2, cnt = enc & 3;
-            for (int k = 0; k < cnt; ++k) consider(S, first + k, ox, oy, oz, dx, dy, dz, best, best_key, work);
-            note_best();
+            const int first = enc >> 3;
+            uint32_t cand = leaf_filter(S->f32s + first, enc & 7, lr);
+#ifdef RT_PROF
+            { uint32_t any_c = cand; while (__any(any_c != 0)) { prof.t[9] += 1; any_c &= any_c - 1; } }
+#endif
+            while (cand != 0) {
+                const int j = __builtin_ctz(cand);
+                cand &= cand - 1;
+                consider(S, first + j, ox, oy, oz, dx, dy, dz, best, best_key, work);
+            }
+            bt = hit_bound(best);
             node = pop();
         }
+        RT_STAMP(prof, 3);
     }
+}
+
+// BVH = false: the reference's linear scan over every sphere (with the f32 filter ahead of the exact tests).
+// BVH = true: the spheres kept out of the tree, then the tree.  A kernel is compiled for each so that neither
+// carries the other's registers.
+template <bool BVH>
+RT_DEV Hit nearest_hit(SceneK S, double ox, double oy, double oz, double dx, double dy, double dz,
+                       bool active, int32_t *stack, int stack_stride, Work &work, Prof &prof)
+{
+    S = fresh(S);
+    Hit best = no_hit();
+    int64_t best_key = 0x7fffffffffffffffLL;
+    if (!BVH) {
+        scan_range<true>(S, 0, S->n, ox, oy, oz, dx, dy, dz, active, best, best_key, work);
+        return best;
+    }
+    always_hits(S, ox, oy, oz, dx, dy, dz, active, best, best_key, work);
+    if (S->n_nodes == 0) return best;
+    const BoxRay br = box_ray(ox, oy, oz, dx, dy, dz, (float)S->box_scale);
+    walk_tree(S, ox, oy, oz, dx, dy, dz, active, br, stack, stack_stride, best, best_key, work, prof);
     return best;
 }
 

@@ -1406,7 +1406,7 @@ namespace {
 
 struct BuildSphere { double c[3], r; int sid; };
 
-// BVH over sphere boxes; children of a node are adjacent; leaves hold <= 2 spheres.
+// BVH over sphere boxes; children of a node are adjacent; leaves hold <= rt3d::LEAF_MAX spheres.
 struct BvhBuilder {
     static constexpr int SWEEP_MAX = 4096; // nodes up to this size are split by the surface-area heuristic
     struct Box {
@@ -1443,7 +1443,7 @@ struct BvhBuilder {
         max_depth = std::max(max_depth, depth);
         rt3d::BvhNode nd{};
         bounds(first, count, nd);
-        if (count <= 2) {
+        if (count <= rt3d::LEAF_MAX) {
             nd.left = first; nd.count = count; nd.axis = 0;
             nodes[(size_t)node] = nd;
             return;
@@ -1547,7 +1547,7 @@ int32_t rt3d_scene_create(rt_ctx *ctx, const rt3d_scene_desc *d, rt3d_scene **ou
             if (std::fabs(d->r[i]) > 64.0 * r_med && always.size() < 32) always.push_back(b);
             else tree.push_back(b);
         }
-        if (tree.size() <= 2) { // no tree worth the name: scan them
+        if (tree.size() <= (size_t)rt3d::LEAF_MAX) { // no tree worth the name: scan them
             always.insert(always.end(), tree.begin(), tree.end());
             tree.clear();
         }
@@ -1572,7 +1572,7 @@ int32_t rt3d_scene_create(rt_ctx *ctx, const rt3d_scene_desc *d, rt3d_scene **ou
                     for (int a = 0; a < 3; ++a) { nodes[i].plane[2 * a][c] = down(ch.lo[a]); nodes[i].plane[2 * a + 1][c] = up(ch.hi[a]); }
                     for (int a = 0; a < 3; ++a) box_scale = std::max(box_scale, std::max(std::fabs(ch.lo[a]), std::fabs(ch.hi[a])));
                     // leaf ranges index the tree list; shift them past the always-tested spheres
-                    nodes[i].child[c] = (ch.count > 0) ? ~(((ch.left + (int)always.size()) << 2) | ch.count) : b.left + c;
+                    nodes[i].child[c] = (ch.count > 0) ? ~(((ch.left + (int)always.size()) << 3) | ch.count) : b.left + c;
                 }
             }
         }
@@ -1610,6 +1610,7 @@ int32_t rt3d_scene_create(rt_ctx *ctx, const rt3d_scene_desc *d, rt3d_scene **ou
         int32_t *sid = c.take<int32_t>(n);
         rt3d::BvhNode2 *nd = c.take<rt3d::BvhNode2>(nodes.size());
         rt3d::SpherePair *f32p = c.take<rt3d::SpherePair>((size_t)np2 / 2);
+        rt3d::SphereF32 *f32s = c.take<rt3d::SphereF32>(nodes.empty() ? 0 : (size_t)n + rt3d::LEAF_MAX); // spare records stay zero
         if (host) {
             char *hb = host->data();
             auto H = [&](auto *p) { return reinterpret_cast<decltype(p)>(hb + (reinterpret_cast<char *>(p) - c.base)); };
@@ -1632,6 +1633,7 @@ int32_t rt3d_scene_create(rt_ctx *ctx, const rt3d_scene_desc *d, rt3d_scene **ou
                     float ef = (float)e;
                     if ((double)ef > e) ef = std::nextafterf(ef, -INFINITY);
                     q.e[h] = inside ? ef : -INFINITY;
+                    if (!nodes.empty()) H(f32s)[k] = rt3d::SphereF32{ fv[0], fv[1], fv[2], q.e[h] };
                     ++k;
                 }
             if (np2 > n) {
@@ -1643,6 +1645,7 @@ int32_t rt3d_scene_create(rt_ctx *ctx, const rt3d_scene_desc *d, rt3d_scene **ou
         }
         S.cx = cx; S.cy = cy; S.cz = cz; S.r2 = r2; S.sid = sid; S.nodes = nd;
         S.f32p = f32p;
+        S.f32s = f32s;
     };
     layout(sz, nullptr);
     const size_t bytes = sz.off + 256;
@@ -1699,6 +1702,15 @@ int32_t rt3d_accumulate(rt_ctx *ctx, const rt3d_scene *scene, const rt3d_render_
     A.tile_counter = reinterpret_cast<int32_t *>(ctx->d_rays + 1);
     A.work_counter = ctx->d_rays + 2;
     A.refill_min = refill_threshold();
+    A.prof_out = nullptr;
+#ifdef RT_PROF
+    {
+        static unsigned long long *d_prof = nullptr;
+        if (!d_prof) { HIP_TRY(hipMalloc((void **)&d_prof, 80 * sizeof(unsigned long long))); }
+        HIP_TRY(hipMemsetAsync(d_prof, 0, 80 * sizeof(unsigned long long), ctx->stream));
+        A.prof_out = d_prof;
+    }
+#endif
     const int64_t tiles = (int64_t)A.tiles_x * ((scene->dev.height + 7) / 8);
     if (tiles > 0x7fffffffLL - 65536) return fail(RT_E_LIMIT, "too many tiles");
     A.n_tiles = (int32_t)tiles;
@@ -1732,6 +1744,18 @@ int32_t rt3d_accumulate(rt_ctx *ctx, const rt3d_scene *scene, const rt3d_render_
     HIP_TRY(hipEventRecord(ev.second, ctx->stream));
     ctx->pending.push_back(ev);
     ctx->launches += 1;
+#ifdef RT_PROF
+    {
+        unsigned long long h[80];
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        HIP_TRY(hipMemcpy(h, A.prof_out, sizeof h, hipMemcpyDeviceToHost));
+        const double tot = (double)(h[0] + h[1] + h[2] + h[3] + h[4]), st = (double)h[5];
+        fprintf(stderr, "[rt_prof3d] wave_steps %llu lanes/step %.2f | per step: inner iterations %.2f, leaf phases %.2f, lanes on a leaf %.2f, "
+                        "exact-test rounds %.2f | cycles/step %.0f: refill %.3f setup+always %.3f walk %.3f leaves %.3f shade %.3f\n",
+                h[5], (double)h[6] / st, (double)h[7] / st, (double)h[8] / st, (double)h[10] / st, (double)h[9] / st, tot / st,
+                h[0] / tot, h[1] / tot, h[2] / tot, h[3] / tot, h[4] / tot);
+    }
+#endif
     ctx->samples += (uint64_t)scene->dev.width * (uint64_t)scene->dev.height * (uint64_t)p->spp;
     return RT_OK;
 }

@@ -941,6 +941,7 @@ struct Render3dArgs {
     int32_t *tile_counter;            // next unit to hand out, zeroed before the launch
     unsigned long long *work_counter; // [0] inner-node visits, [1] exact sphere tests
     int32_t refill_min;
+    unsigned long long *prof_out; // diagnostic builds only
 };
 
 // Generated primary rays of one wave (the origin is the camera position for all of them).
@@ -989,7 +990,10 @@ __global__ __launch_bounds__(BLOCK, 5) void render3d_kernel(const Render3dArgs A
     unsigned long long nrays = 0;
     rt3d::Work work{ 0u, 0u };
     const int total = TILE_PIXELS * Ak->spp;
-
+    rtd::Prof prof{};
+#ifdef RT_PROF
+    prof.last = __builtin_amdgcn_s_memtime();
+#endif
     // adds the wave's accumulator to the image and clears it
     auto flush = [&](int ftx, int fty) {
         __builtin_amdgcn_wave_barrier();
@@ -1006,7 +1010,32 @@ __global__ __launch_bounds__(BLOCK, 5) void render3d_kernel(const Render3dArgs A
         acc[lane] = 0.0f; acc[lane + 64] = 0.0f; acc[lane + 128] = 0.0f;
         __builtin_amdgcn_wave_barrier();
     };
-
+    // the colour a finished path returns goes to its pixel
+    auto deposit = [&](const float rgb[3]) {
+        if (rgb[0] != 0.0f || rgb[1] != 0.0f || rgb[2] != 0.0f) {
+            if (my_unit == unit_no) {
+                atomicAdd(&acc[lpix * 3 + 0], rgb[0]);
+                atomicAdd(&acc[lpix * 3 + 1], rgb[1]);
+                atomicAdd(&acc[lpix * 3 + 2], rgb[2]);
+            } else {
+                float *dst = Ak->out + (int64_t)gpix * 3;
+                unsafeAtomicAdd(dst + 0, rgb[0]);
+                unsafeAtomicAdd(dst + 1, rgb[1]);
+                unsafeAtomicAdd(dst + 2, rgb[2]);
+            }
+        }
+    };
+    // the body of trace_ray after the search, for the lanes in `run`
+    auto shade_step = [&](bool run, const rt3d::Hit &h) {
+        if (run) {
+            ++nrays;
+            float rgb[3];
+            if (rt3d::shade((rt3d::SceneK)&Ak->S, p, h, Ak->bounce_limit, Ak->k0, Ak->k1, rgb)) {
+                deposit(rgb);
+                alive = false;
+            }
+        }
+    };
     while (true) {
         asm volatile("" : "+s"(Ak)); // arguments are re-read where a step needs them, not held in registers across it
         const uint64_t dead = __ballot(!alive);
@@ -1079,27 +1108,20 @@ __global__ __launch_bounds__(BLOCK, 5) void render3d_kernel(const Render3dArgs A
             if (exhausted && pool_pos >= pool_items) break;
             continue;
         }
-        const rt3d::Hit h = rt3d::nearest_hit<BVH>((rt3d::SceneK)&Ak->S, p.ox, p.oy, p.oz, p.dx, p.dy, p.dz, alive, stack + tid, BLOCK, work);
-        if (alive) {
-            ++nrays;
-            float rgb[3];
-            if (rt3d::shade((rt3d::SceneK)&Ak->S, p, h, Ak->bounce_limit, Ak->k0, Ak->k1, rgb)) {
-                if (rgb[0] != 0.0f || rgb[1] != 0.0f || rgb[2] != 0.0f) {
-                    if (my_unit == unit_no) {
-                        atomicAdd(&acc[lpix * 3 + 0], rgb[0]);
-                        atomicAdd(&acc[lpix * 3 + 1], rgb[1]);
-                        atomicAdd(&acc[lpix * 3 + 2], rgb[2]);
-                    } else {
-                        float *dst = Ak->out + (int64_t)gpix * 3;
-                        unsafeAtomicAdd(dst + 0, rgb[0]);
-                        unsafeAtomicAdd(dst + 1, rgb[1]);
-                        unsafeAtomicAdd(dst + 2, rgb[2]);
-                    }
-                }
-                alive = false;
-            }
-        }
+        RT_STAMP(prof, 0);
+#ifdef RT_PROF
+        prof.t[5] += 1;
+        prof.t[6] += (unsigned long long)__popcll(__ballot(alive));
+#endif
+        const rt3d::Hit h = rt3d::nearest_hit<BVH>((rt3d::SceneK)&Ak->S, p.ox, p.oy, p.oz, p.dx, p.dy, p.dz, alive, stack + tid, BLOCK, work, prof);
+        RT_STAMP(prof, 3);
+        shade_step(alive, h);
+        RT_STAMP(prof, 4);
     }
+#ifdef RT_PROF
+    if (lane == 0 && Ak->prof_out)
+        for (int i = 0; i < 16; ++i) atomicAdd(Ak->prof_out + i, prof.t[i]);
+#endif
     // the last unit's accumulator was flushed when the wave found no further unit
     for (int off = 32; off > 0; off >>= 1) {
         nrays += __shfl_down(nrays, off);
@@ -1126,6 +1148,7 @@ __global__ __launch_bounds__(BLOCK) void trace_batch3d_kernel(const rt3d::SceneD
     const rt3d::SceneK Sk = (rt3d::SceneK)__builtin_amdgcn_kernarg_segment_ptr(); // S is the first argument
     (void)S;
     rt3d::Work work{ 0u, 0u };
+    rtd::Prof prof{};
     const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     const bool in_range = i < n;
     rt3d::Path p;
@@ -1140,7 +1163,7 @@ __global__ __launch_bounds__(BLOCK) void trace_batch3d_kernel(const rt3d::SceneD
     int nb = 0, fp = -1;
     double ft = -1.0;
     while (__any(alive)) {
-        const rt3d::Hit h = rt3d::nearest_hit<BVH>(Sk, p.ox, p.oy, p.oz, p.dx, p.dy, p.dz, alive, stack + threadIdx.x, BLOCK, work);
+        const rt3d::Hit h = rt3d::nearest_hit<BVH>(Sk, p.ox, p.oy, p.oz, p.dx, p.dy, p.dz, alive, stack + threadIdx.x, BLOCK, work, prof);
         if (alive) {
             if (nb == 0 && h.slot >= 0) { fp = h.sid; ft = h.t; }
             ++nb;
