@@ -314,11 +314,16 @@ RT_DEV void scan_range(SceneK S, int first, int last, double ox, double oy, doub
 // Conservative in three steps: (1) the boxes are rounded outward on the host; (2) c's own error - o rounded to f32
 // and the fused step's rounding, together < 2.1 * 2^-24 |o| |idf| - is below a quarter of the pad
 // 2^-21 (|o|_inf + scene scale) |idf|, which moves the near bound down and the far bound up; (3) idf carries a relative
-// error <= 2^-23 and the step that forms t another 2^-24: the bounds are moved apart by 2^-20 |t| (one fused step each,
-// a single rounding, well inside the slack).  hit[c] = the padded interval of child c reaches t >= 0 and starts at or
-// before `bt`; tn[c] = its lower end.  NaN (0 * inf: origin on a slab plane of an axis-parallel ray) is dropped by
-// min / max: conservative.  (Fetching near and far planes by per-lane offsets instead - no min / max per axis - cuts
-// another 12 instructions and was slower, 27.5 against 32.4 Grays/s: seven divergent loads per visit instead of four.)
+// error <= 2^-23 (v_rcp_f32 is good to one unit in the last place) and the step that forms t another 2^-24: the bounds
+// are moved apart by 2^-20 |t| (one fused step each, a single rounding, well inside the slack).
+// A direction component below 2^-60 in size (zero included) is taken as +-2^-60: idf stays finite, so no step ever
+// meets 0 * inf, and the decision is the one the true component gives - an origin inside the padded slab sees t of
+// opposite signs and astronomic size on its two planes (the axis constrains nothing), an origin outside sees both
+// beyond 2^39 (|o|_inf + scale) on one side, farther than any sphere of the tree can be hit, while with the true
+// component the slab is reached later still.
+// hit[c] = the padded interval of child c reaches t >= 0 and starts at or before `bt`; tn[c] = its lower end.
+// (Fetching near and far planes by per-lane offsets instead - no min / max per axis - cuts another 12 instructions and
+// was slower, 27.5 against 32.4 Grays/s: seven divergent loads per visit instead of four.)
 struct BoxRay {
     float idf[3], c_lo[3], c_hi[3];
 };
@@ -331,7 +336,7 @@ RT_DEV BoxRay box_ray(double ox, double oy, double oz, double dx, double dy, dou
     BoxRay r;
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-        r.idf[a] = 1.0f / df[a];
+        r.idf[a] = __builtin_amdgcn_rcpf(__builtin_copysignf(__builtin_fmaxf(__builtin_fabsf(df[a]), 0x1.0p-60f), df[a]));
         // pad * idf has the direction's sign: subtracting it lowers t on the low plane when that one is the near plane
         // (d >= 0) and raises it when it is the far one
         const float padt = pad * r.idf[a];

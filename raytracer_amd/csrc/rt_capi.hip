@@ -1425,7 +1425,8 @@ struct BvhBuilder {
     std::vector<rt3d::BvhNode> nodes;
     int max_depth = 0;
     double pad;
-    explicit BvhBuilder(std::vector<BuildSphere> &s, double pad_) : sp(s), pad(pad_) {}
+    bool median_only; // every node split at the median: depth <= log2(count) + 1 whatever the input
+    explicit BvhBuilder(std::vector<BuildSphere> &s, double pad_, bool median_only_ = false) : sp(s), pad(pad_), median_only(median_only_) {}
 
     void bounds(int first, int count, rt3d::BvhNode &nd)
     {
@@ -1443,7 +1444,8 @@ struct BvhBuilder {
         max_depth = std::max(max_depth, depth);
         rt3d::BvhNode nd{};
         bounds(first, count, nd);
-        if (count <= rt3d::LEAF_MAX) {
+        // (a branch already deeper than the traversal stack allows is cut short: the caller builds the tree again)
+        if (count <= rt3d::LEAF_MAX || (depth > rt3d::BVH_STACK && !median_only)) {
             nd.left = first; nd.count = count; nd.axis = 0;
             nodes[(size_t)node] = nd;
             return;
@@ -1454,7 +1456,7 @@ struct BvhBuilder {
             };
         };
         int axis = 0, mid = first + count / 2;
-        if (count <= SWEEP_MAX) {
+        if (count <= SWEEP_MAX && !median_only) {
             // surface-area heuristic, full sweep: for every axis sort by centre and price every split position
             // as area(left) * n_left + area(right) * n_right; the cheapest (axis, position) wins
             double best = INFINITY;
@@ -1467,7 +1469,8 @@ struct BvhBuilder {
                 for (int i = 1; i < count; ++i) {
                     l.add(sp[(size_t)(first + i - 1)]);
                     const double cost = l.half_area() * i + right_area[(size_t)i] * (count - i);
-                    if (cost < best) { best = cost; axis = a; mid = first + i; }
+                    // equal prices (coincident centres price every position alike): the more balanced split
+                    if (cost < best || (cost == best && std::abs(2 * i - count) < std::abs(2 * (mid - first) - count))) { best = cost; axis = a; mid = first + i; }
                 }
             }
             if (axis != 2) std::sort(sp.begin() + first, sp.begin() + first + count, by_axis(axis));
@@ -1558,6 +1561,14 @@ int32_t rt3d_scene_create(rt_ctx *ctx, const rt3d_scene_desc *d, rt3d_scene **ou
             BvhBuilder bb(tree, 1e-7 * scale);
             bb.nodes.emplace_back();
             bb.build(0, 0, (int)tree.size(), 1);
+            if (bb.max_depth > rt3d::BVH_STACK) {
+                // a tree the surface-area splits made too deep for the traversal stack (spheres nested like onion
+                // skins do that): median splits bound the depth by log2(2^24) + 1
+                bb.median_only = true;
+                bb.nodes.assign(1, rt3d::BvhNode{});
+                bb.max_depth = 0;
+                bb.build(0, 0, (int)tree.size(), 1);
+            }
             if (bb.max_depth > rt3d::BVH_STACK) return fail(RT_E_LIMIT, "BVH deeper than %d levels", rt3d::BVH_STACK);
             stack_levels = std::max(bb.max_depth, 1);
             // traversal nodes: one per build node (leaf entries stay unused), children's boxes rounded outward to f32

@@ -124,3 +124,32 @@ def test_walk_counters_describe_the_tree_walk(gpu_ctx):
             assert st["rays"] < st["bvh_node_visits"] < 20 * st["rays"] and st["rays"] <= st["sphere_tests"] < 10 * st["rays"]
         else:
             assert st["bvh_node_visits"] == 0 and st["sphere_tests"] > 0
+
+
+@pytest.mark.parametrize("use_bvh", [False, True])
+def test_directions_with_zero_components(use_bvh, gpu_ctx, oracle):
+    """Rays parallel to one or two axes (direction components exactly +-0), from inside and from outside the slabs of
+    the tree's boxes along the axes they do not move on: the box test must neither lose a hit nor depend on 0 x inf."""
+    s = rt.Standalone3D(64, 48, use_bvh=use_bvh)
+    scene = rt.Scene3D(gpu_ctx, s)
+    rng = np.random.default_rng(21)
+    m = 60_000
+    # origins in and around the grid of spheres (x, y in -7.5 .. 7.5 about (0, 2), z in -27.5 .. -12.5) and far from it
+    o = rng.uniform(-14.0, 14.0, (m, 3)) * rng.choice([1.0, 1.0, 3.0], (m, 1)) + [0.0, 2.0, -20.0]
+    # some origins exactly on the lattice of sphere centres' coordinates: the rays then run through centres
+    snap = rng.random(m) < 0.3
+    o[snap] = np.round((o[snap] - [0.0, 2.0, -20.0]) / 3.0) * 3.0 + [-1.5, 0.5, -21.5] + rng.choice([0.0, 0.8, -0.8], (int(snap.sum()), 3))
+    d = np.zeros((m, 3))
+    axis = rng.integers(0, 3, m)
+    d[np.arange(m), axis] = rng.choice([-1.0, 1.0], m)
+    two = rng.random(m) < 0.4                       # a second non-zero component: the ray lies in an axis plane
+    a2 = (axis + rng.integers(1, 3, m)) % 3
+    d[np.arange(m)[two], a2[two]] = rng.normal(0, 1, int(two.sum()))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    d[rng.random(m) < 0.5] *= 1.0                    # keep +0
+    neg = rng.random((m, 3)) < 0.5
+    d = np.where((d == 0.0) & neg, -0.0, d)          # and -0
+    got, want = scene.trace_batch(o, d, 6, seed=12), oracle.trace_batch3d(s, o, d, 6, seed=12)
+    compare(got, want)
+    assert 0.1 < (want[1] >= 0).mean() < 0.999
+    scene.close()

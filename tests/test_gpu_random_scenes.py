@@ -189,6 +189,7 @@ def random_scene3d(rng, n, giant, use_bvh, w=32, h=24):
 
 
 def compare3d(got, want):
+    got, want = list(got), list(want)
     for x, y in zip(got[1:], want[1:]):
         assert np.array_equal(x, y)
     assert np.allclose(got[0], want[0], rtol=1e-5, atol=1e-30)
@@ -214,6 +215,88 @@ def test_random_spheres_fed_batch(n, giant, use_bvh, gpu_ctx, oracle):
     d /= np.linalg.norm(d, axis=1, keepdims=True)
     compare3d(scene.trace_batch(o, d, 10, seed=8), oracle.trace_batch3d(s, o, d, 10, seed=8))
     scene.close()
+
+
+def timed_grays(ctx, scene, spp=16):
+    """Kernel rate of one small render (HIP events around the launch), Grays/s."""
+    scene.render(params3d(1, 10, seed=1))
+    ctx.reset_stats()
+    scene.render(params3d(spp, 10, seed=1))
+    st = ctx.stats()
+    return st["rays"] / st["kernel_ms"] / 1e6
+
+
+@pytest.mark.parametrize("n", [5_000, 20_000])
+def test_large_scenes_take_the_median_split_path(n, gpu_ctx, oracle, capsys):
+    """Scenes above the 4096 spheres up to which a node is split by the surface-area sweep: the top of the tree is
+    split at the median.  The BVH must return the linear scan's hits bit for bit (both on the GPU, 40 k rays), and both
+    the checker's on a part of the rays; the two kernels' rates at this size are printed for the record."""
+    rng = np.random.default_rng(n)
+    c = rng.uniform(-20.0, 20.0, (n, 3))
+    r = np.exp(rng.uniform(np.log(0.05), np.log(0.5), n))
+    c[n - 1], r[n - 1] = (0.0, -5020.0, 0.0), 5000.0
+    c[1] = c[0]
+    c[3], r[3] = c[2], r[2]
+    d0 = np.array([0.2, -0.1, -1.0]) / np.linalg.norm([0.2, -0.1, -1.0])
+    up = np.cross(np.cross(d0, [0.0, 1.0, 0.0]), d0)
+    up /= np.linalg.norm(up)
+    scenes = {b: rt.ArrayScene3D(c[:, 0], c[:, 1], c[:, 2], r, (1.0, 3.0, 30.0), d0, up, 1.5, 640, 480, use_bvh=b) for b in (False, True)}
+    lin, bvh = rt.Scene3D(gpu_ctx, scenes[False]), rt.Scene3D(gpu_ctx, scenes[True])
+    m = 40_000
+    o = rng.uniform(-25.0, 25.0, (m, 3))
+    d = rng.normal(0, 1, (m, 3))
+    k = rng.integers(0, n, m)
+    t = rng.normal(0, 1, (m, 3))
+    t -= (t * (c[k] - o)).sum(1, keepdims=True) * (c[k] - o) / ((c[k] - o) ** 2).sum(1, keepdims=True)
+    t /= np.linalg.norm(t, axis=1, keepdims=True)
+    rim = c[k] + t * r[k][:, None] * (1.0 + rng.choice([0.0, 1e-15, -1e-15, 1e-9, -1e-9, 1e-4], m))[:, None]
+    d = np.where((rng.random(m) < 1 / 3)[:, None], rim - o, d)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    a, b = lin.trace_batch(o, d, 10, seed=8), bvh.trace_batch(o, d, 10, seed=8)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+    compare3d((x[:4000] for x in b), oracle.trace_batch3d(scenes[True], o[:4000], d[:4000], 10, seed=8))
+    assert (b[1] >= 0).mean() > 0.5
+    rates = {name: timed_grays(gpu_ctx, sc) for name, sc in (("linear scan", lin), ("BVH", bvh))}
+    with capsys.disabled():
+        print(f"\n[3d, {n} spheres, 640x480, 16 spp] linear scan {rates['linear scan']:.2f} Grays/s, BVH {rates['BVH']:.2f} Grays/s")
+    lin.close()
+    bvh.close()
+
+
+@pytest.mark.parametrize("kind", ["coincident", "collinear", "onion"])
+def test_degenerate_scenes_build_and_match(kind, gpu_ctx, oracle):
+    """Inputs that drive a surface-area tree deep: thousands of spheres with ONE centre (every split position costs
+    the same), centres on a line, and spheres nested like onion skins (each split peels one off).  The builder must
+    stay within the traversal stack - balanced ties, median splits as the last resort - and the walk must return the
+    linear scan's hits, lowest index first among equals."""
+    rng = np.random.default_rng(5)
+    n = 6000
+    if kind == "coincident":
+        c = np.tile([1.0, 2.0, -3.0], (n, 1))
+        r = np.full(n, 1.5)
+        r[n // 2:] = 0.75                                   # two radii: exact ties within each half
+    elif kind == "collinear":
+        c = np.stack([np.linspace(-30.0, 30.0, n), np.full(n, 2.0), np.full(n, -3.0)], 1)
+        r = np.full(n, 0.2)
+    else:
+        c = np.tile([0.0, 0.0, 0.0], (n, 1)) + rng.normal(0, 1e-3, (n, 3))
+        r = np.exp(np.linspace(np.log(0.01), np.log(40.0), n))
+    d0 = np.array([0.0, 0.0, -1.0])
+    scenes = {b: rt.ArrayScene3D(c[:, 0], c[:, 1], c[:, 2], r, (0.0, 0.0, 60.0), d0, (0.0, 1.0, 0.0), 1.5, 32, 24, use_bvh=b) for b in (False, True)}
+    lin, bvh = rt.Scene3D(gpu_ctx, scenes[False]), rt.Scene3D(gpu_ctx, scenes[True])
+    m = 20_000
+    o = rng.uniform(-45.0, 45.0, (m, 3))
+    aim = c[rng.integers(0, n, m)] + rng.normal(0, 1, (m, 3)) * r[rng.integers(0, n, m)][:, None]
+    d = np.where((rng.random(m) < 0.7)[:, None], aim - o, rng.normal(0, 1, (m, 3)))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    a, b = lin.trace_batch(o, d, 4, seed=2), bvh.trace_batch(o, d, 4, seed=2)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+    compare3d((x[:3000] for x in b), oracle.trace_batch3d(scenes[True], o[:3000], d[:3000], 4, seed=2))
+    assert (b[1] >= 0).mean() > 0.3
+    lin.close()
+    bvh.close()
 
 
 @pytest.mark.parametrize("use_bvh", [False, True])

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""Copies the judged summaries of one tools/profile_r1.sh run from gpurun_out/ into profiles/<dest>/:
-the rocprofv3 --kernel-trace --stats table and the per-dispatch PMC averages of the render kernel
-(FETCH_SIZE doubled as the gfx950 guide prescribes for wide coalesced reads).
+"""Copies the judged summaries of one tools/profile_r3.sh (or profile_r1.sh / profile_r2.sh) run from gpurun_out/
+into profiles/<dest>/: the rocprofv3 --kernel-trace --stats table and the per-dispatch PMC averages of the render
+kernel (FETCH_SIZE doubled as the gfx950 guide prescribes for wide coalesced reads; the per-type VALU instruction and
+FLOP counters of the pmc_flop passes, when they were run).
 Usage: python tools/collect_profiles.py <tag> <dest> [kernel-substring]"""
 import collections
 import csv
@@ -18,7 +19,7 @@ os.makedirs(dest, exist_ok=True)
 stats = glob.glob(os.path.join(src, "trace", "**", "*_kernel_stats.csv"), recursive=True)[0]
 shutil.copy(stats, os.path.join(dest, f"kernel_stats_{tag}.csv"))
 out = {}
-for name in ("pmc_sq1", "pmc_sq2", "pmc_fetch", "pmc_write"):
+for name in ("pmc_sq1", "pmc_sq2", "pmc_fetch", "pmc_write", "pmc_flop1", "pmc_flop2"):
     files = glob.glob(os.path.join(src, name, "**", "*_counter_collection.csv"), recursive=True)
     if not files:
         continue
