@@ -874,7 +874,7 @@ int32_t rt2d_resolve(rt_ctx *ctx, const void *d_spectrum, int32_t width, int32_t
         if (!rgb) rgb = (float *)ws;
         w = (float *)ws + npx * 3;
     }
-    const unsigned blocks = (unsigned)((npx + 63) / 64);
+    const unsigned blocks = (unsigned)((npx + rtk::STAGE_PIXELS - 1) / rtk::STAGE_PIXELS);
     hipLaunchKernelGGL(rtk::resolve2d_kernel, dim3(blocks), dim3(64), 0, ctx->stream, (const float *)d_spectrum, npx,
                        (float)total_spp, rgb, out_weight ? w : nullptr);
     HIP_TRY(hipGetLastError());
@@ -890,7 +890,7 @@ int32_t rt2d_project_xyz(rt_ctx *ctx, const void *d_spectrum, int32_t width, int
     if (!d_spectrum || !d_xyz) return fail(RT_E_INVALID, "null device buffer");
     if (width <= 0 || height <= 0) return fail(RT_E_INVALID, "sizes must be positive");
     const int64_t npx = (int64_t)width * height;
-    hipLaunchKernelGGL(rtk::project_xyz_kernel, dim3((unsigned)((npx + 63) / 64)), dim3(64), 0, ctx->stream, (const float *)d_spectrum,
+    hipLaunchKernelGGL(rtk::project_xyz_kernel, dim3((unsigned)((npx + rtk::STAGE_PIXELS - 1) / rtk::STAGE_PIXELS)), dim3(64), 0, ctx->stream, (const float *)d_spectrum,
                        npx, (float *)d_xyz);
     HIP_TRY(hipGetLastError());
     return RT_OK;
@@ -1012,7 +1012,7 @@ int32_t rt2d_denoise_device(rt_ctx *ctx, const rt2d_scene *scene, const rt2d_ren
     const double lo_px[2] = { (double)-m, (double)-m }, hi_px[2] = { (double)(W - 1 + m), (double)(H - 1 + m) };
     // list mode 2: accumulated sums; denoise_add_kernel divides by spp as it reads them
     if (int32_t rc = launch_render2d(ctx, scene, p, 2, px.count, px.lx, px.ly, px.spec, lo_px, hi_px)) return rc;
-    hipLaunchKernelGGL(rtk::denoise_add_kernel, dim3((unsigned)((px.count + 63) / 64)), dim3(64), 0, ctx->stream, px.spec, px.lx, px.ly,
+    hipLaunchKernelGGL(rtk::denoise_add_kernel, dim3((unsigned)((px.count + rtk::STAGE_PIXELS - 1) / rtk::STAGE_PIXELS)), dim3(64), 0, ctx->stream, px.spec, px.lx, px.ly,
                        px.count, W, H, (float)p->spp, (float)p->spp * oversampling_factor, (float *)d_merged_rgb,
                        (float *)d_merged_weight);
     HIP_TRY(hipGetLastError());
@@ -1131,7 +1131,7 @@ int32_t rt2d_progressive_resample(rt2d_progressive *g, int64_t *out_recomputed)
     if (int32_t rc = check_params2d(&q)) return rc;
     const double lo_px[2] = { (double)-m, (double)-m }, hi_px[2] = { (double)(W - 1 + m), (double)(H - 1 + m) };
     if (int32_t rc = launch_render2d(ctx, g->scene, &q, 2, px.count, px.lx, px.ly, px.spec, lo_px, hi_px)) return rc;
-    hipLaunchKernelGGL(rtk::progressive_add_kernel, dim3((unsigned)((px.count + 63) / 64)), dim3(64), 0, ctx->stream, px.spec, px.lx,
+    hipLaunchKernelGGL(rtk::progressive_add_kernel, dim3((unsigned)((px.count + rtk::STAGE_PIXELS - 1) / rtk::STAGE_PIXELS)), dim3(64), 0, ctx->stream, px.spec, px.lx,
                        px.ly, px.count, W, H, (float)spp_r, g->sum, g->count, g->merged_rgb);
     HIP_TRY(hipGetLastError());
     g->next_sample += spp_r;

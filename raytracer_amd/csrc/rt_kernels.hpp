@@ -545,38 +545,73 @@ RT_DEV float srgb_channel(float c)
     return (e < 0.0f) ? 0.0f : (e > 1.0f) ? 1.0f : e;
 }
 
-// Spectrum::to_xyz + to_dvec3 (2d/src/spectrum.rs:242-278) of accumulated / total_spp;
-// the XYZ(D65) -> sRGB step is palette's: linear matrix, then the sRGB transfer
-// function, clamped to [0, 1].  One wave per 64 pixels: coalesced load of the 64 spectra
-// into LDS, then one lane per pixel sums its 95 bins in index order.
-__global__ __launch_bounds__(64) void resolve2d_kernel(const float *__restrict__ spectrum, int64_t n_pixels,
-                                                      float total_spp, float *__restrict__ rgb,
-                                                      float *__restrict__ weight)
+// The per-pixel kernels below read whole spectra (95 floats, 380 B per pixel) and are bound by HBM: a wave takes
+// STAGE_PIXELS = 32 consecutive pixels - 12 160 contiguous bytes, 16-byte aligned when the plane is - through LDS with
+// 16-byte loads, several in flight per lane, and one lane per pixel then sums its 95 bins in index order (the
+// reference's order).  12 KB of LDS per one-wave workgroup leaves 13 of them resident per CU; the first version
+// (64 pixels and 24 KB per wave, 4-byte loads) had 6 and reached 1.4 TB/s.
+constexpr int STAGE_PIXELS = 32;
+
+// Bins of `cnt` <= STAGE_PIXELS consecutive pixels from `src` into `sp`, every value passed through `f`.
+template <class F>
+RT_DEV void stage_spectra(const float *__restrict__ src, int cnt, float *sp, F f)
 {
-    __shared__ float sp[64 * NBINS];
-    const int64_t first = (int64_t)blockIdx.x * 64;
-    const int64_t cnt = (n_pixels - first < 64) ? (n_pixels - first) : 64;
-    const float *src = spectrum + first * NBINS;
-    for (int i = threadIdx.x; i < cnt * NBINS; i += 64) sp[i] = src[i];
-    __syncthreads();
-    const int lane = threadIdx.x;
-    if (lane >= cnt) return;
-    float x = 0.0f, y = 0.0f, z = 0.0f;
+    const int nf = cnt * NBINS;
+    int done = 0;
+    if ((reinterpret_cast<uintptr_t>(src) & 15) == 0) {
+        const int nv = nf / 4;
+#pragma unroll 4
+        for (int i = threadIdx.x; i < nv; i += 64) {
+            float4 a = reinterpret_cast<const float4 *>(src)[i];
+            a.x = f(a.x); a.y = f(a.y); a.z = f(a.z); a.w = f(a.w);
+            reinterpret_cast<float4 *>(sp)[i] = a;
+        }
+        done = nv * 4;
+    }
+    for (int i = done + threadIdx.x; i < nf; i += 64) sp[i] = f(src[i]);
+}
+
+// Spectrum::to_xyz (2d/src/spectrum.rs:242-254) of one staged pixel: sums in index order, unfused.
+RT_DEV void staged_to_xyz(const float *sp, float &x, float &y, float &z)
+{
+    x = 0.0f; y = 0.0f; z = 0.0f;
     for (int b = 0; b < NBINS; ++b) {
-        const float v = sp[lane * NBINS + b] / total_spp;
+        const float v = sp[b];
         x = x + v * CMF[3 * b + 0];
         y = y + v * CMF[3 * b + 1];
         z = z + v * CMF[3 * b + 2];
     }
+}
+
+// to_dvec3 after to_xyz (2d/src/spectrum.rs:256-278): palette's XYZ(D65) -> sRGB matrix, transfer function, clamp.
+RT_DEV void xyz_to_srgb(float x, float y, float z, float out[3])
+{
     float lin[3];
     lin[0] = 3.2404542f * x + -1.5371385f * y + -0.4985314f * z;
     lin[1] = -0.9692660f * x + 1.8760108f * y + 0.0415560f * z;
     lin[2] = 0.0556434f * x + -0.2040259f * y + 1.0572252f * z;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) out[k] = srgb_channel(lin[k]);
+}
+
+// Spectrum::to_xyz + to_dvec3 (2d/src/spectrum.rs:242-278) of accumulated / total_spp.
+__global__ __launch_bounds__(64) void resolve2d_kernel(const float *__restrict__ spectrum, int64_t n_pixels,
+                                                      float total_spp, float *__restrict__ rgb,
+                                                      float *__restrict__ weight)
+{
+    __shared__ __align__(16) float sp[STAGE_PIXELS * NBINS];
+    const int64_t first = (int64_t)blockIdx.x * STAGE_PIXELS;
+    const int cnt = (int)((n_pixels - first < STAGE_PIXELS) ? (n_pixels - first) : STAGE_PIXELS);
+    stage_spectra(spectrum + first * NBINS, cnt, sp, [=](float v) { return v / total_spp; });
+    __syncthreads();
+    const int lane = threadIdx.x;
+    if (lane >= cnt) return;
+    float x, y, z, out[3];
+    staged_to_xyz(sp + lane * NBINS, x, y, z);
+    xyz_to_srgb(x, y, z, out);
     const int64_t pix = first + lane;
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        rgb[pix * 3 + k] = srgb_channel(lin[k]);
-    }
+    for (int k = 0; k < 3; ++k) rgb[pix * 3 + k] = out[k];
     if (weight) weight[pix] = total_spp;
 }
 
@@ -585,21 +620,15 @@ __global__ __launch_bounds__(64) void resolve2d_kernel(const float *__restrict__
 // 380 (their spectra).  project: xyz[pix] = sum over bins, in index order, of spectrum[pix][b] * CMF[b] (no division).
 __global__ __launch_bounds__(64) void project_xyz_kernel(const float *__restrict__ spectrum, int64_t n_pixels, float *__restrict__ xyz)
 {
-    __shared__ float sp[64 * NBINS];
-    const int64_t first = (int64_t)blockIdx.x * 64;
-    const int64_t cnt = (n_pixels - first < 64) ? (n_pixels - first) : 64;
-    const float *src = spectrum + first * NBINS;
-    for (int i = threadIdx.x; i < cnt * NBINS; i += 64) sp[i] = src[i];
+    __shared__ __align__(16) float sp[STAGE_PIXELS * NBINS];
+    const int64_t first = (int64_t)blockIdx.x * STAGE_PIXELS;
+    const int cnt = (int)((n_pixels - first < STAGE_PIXELS) ? (n_pixels - first) : STAGE_PIXELS);
+    stage_spectra(spectrum + first * NBINS, cnt, sp, [](float v) { return v; });
     __syncthreads();
     const int lane = threadIdx.x;
     if (lane >= cnt) return;
-    float x = 0.0f, y = 0.0f, z = 0.0f;
-    for (int b = 0; b < NBINS; ++b) {
-        const float v = sp[lane * NBINS + b];
-        x = x + v * CMF[3 * b + 0];
-        y = y + v * CMF[3 * b + 1];
-        z = z + v * CMF[3 * b + 2];
-    }
+    float x, y, z;
+    staged_to_xyz(sp + lane * NBINS, x, y, z);
     const int64_t pix = first + lane;
     xyz[pix * 3 + 0] = x; xyz[pix * 3 + 1] = y; xyz[pix * 3 + 2] = z;
 }
@@ -611,14 +640,10 @@ __global__ __launch_bounds__(BLOCK) void encode_xyz_kernel(const float *__restri
     const int64_t pix = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (pix >= n_pixels) return;
     const float x = xyz[pix * 3 + 0] / total_spp, y = xyz[pix * 3 + 1] / total_spp, z = xyz[pix * 3 + 2] / total_spp;
-    float lin[3];
-    lin[0] = 3.2404542f * x + -1.5371385f * y + -0.4985314f * z;
-    lin[1] = -0.9692660f * x + 1.8760108f * y + 0.0415560f * z;
-    lin[2] = 0.0556434f * x + -0.2040259f * y + 1.0572252f * z;
+    float out[3];
+    xyz_to_srgb(x, y, z, out);
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        rgb[pix * 3 + k] = srgb_channel(lin[k]);
-    }
+    for (int k = 0; k < 3; ++k) rgb[pix * 3 + k] = out[k];
     if (weight) weight[pix] = total_spp;
 }
 
@@ -771,32 +796,21 @@ __global__ __launch_bounds__(64) void denoise_add_kernel(const float *__restrict
                                                         const int32_t *__restrict__ py, int64_t n, int W, int H, float spp,
                                                         float wadd, float *__restrict__ rgb, float *__restrict__ weight)
 {
-    __shared__ float sp[64 * NBINS];
-    const int64_t first = (int64_t)blockIdx.x * 64;
-    const int64_t cnt = (n - first < 64) ? (n - first) : 64;
-    const float *src = spectrum + first * NBINS;
-    for (int i = threadIdx.x; i < cnt * NBINS; i += 64) sp[i] = src[i] / spp; // `spectrum / spp`, librt2d_reverse.rs:109
+    __shared__ __align__(16) float sp[STAGE_PIXELS * NBINS];
+    const int64_t first = (int64_t)blockIdx.x * STAGE_PIXELS;
+    const int cnt = (int)((n - first < STAGE_PIXELS) ? (n - first) : STAGE_PIXELS);
+    stage_spectra(spectrum + first * NBINS, cnt, sp, [=](float v) { return v / spp; }); // `spectrum / spp`, librt2d_reverse.rs:109
     __syncthreads();
     const int lane = threadIdx.x;
     if (lane >= cnt) return;
     const int x = px[first + lane], y = py[first + lane];
     if (x < 0 || y < 0 || x >= W || y >= H) return; // pixel_to_idx -> Err, ignored by the reference
-    float X = 0.0f, Y = 0.0f, Z = 0.0f;
-    for (int b = 0; b < NBINS; ++b) {
-        const float v = sp[lane * NBINS + b];
-        X = X + v * CMF[3 * b + 0];
-        Y = Y + v * CMF[3 * b + 1];
-        Z = Z + v * CMF[3 * b + 2];
-    }
-    float lin[3];
-    lin[0] = 3.2404542f * X + -1.5371385f * Y + -0.4985314f * Z;
-    lin[1] = -0.9692660f * X + 1.8760108f * Y + 0.0415560f * Z;
-    lin[2] = 0.0556434f * X + -0.2040259f * Y + 1.0572252f * Z;
+    float X, Y, Z, out[3];
+    staged_to_xyz(sp + lane * NBINS, X, Y, Z);
+    xyz_to_srgb(X, Y, Z, out);
     const int64_t pix = (int64_t)W * y + x; // every pixel appears once in the list: no atomics needed
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        rgb[pix * 3 + k] = rgb[pix * 3 + k] + srgb_channel(lin[k]);
-    }
+    for (int k = 0; k < 3; ++k) rgb[pix * 3 + k] = rgb[pix * 3 + k] + out[k];
     weight[pix] = weight[pix] + wadd;
 }
 
@@ -815,19 +829,15 @@ RT_DEV void spectrum_to_srgb(const float *sp, float div, float out[3])
         y = y + v * CMF[3 * b + 1];
         z = z + v * CMF[3 * b + 2];
     }
-    float lin[3];
-    lin[0] = 3.2404542f * x + -1.5371385f * y + -0.4985314f * z;
-    lin[1] = -0.9692660f * x + 1.8760108f * y + 0.0415560f * z;
-    lin[2] = 0.0556434f * x + -0.2040259f * y + 1.0572252f * z;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        out[k] = srgb_channel(lin[k]);
-    }
+    xyz_to_srgb(x, y, z, out);
 }
 
 // One whole-image pass of `spp` samples per pixel joins the running sums: sum += pass, count += spp, and both
 // images the noise estimate compares are refreshed: loop_rgb = sRGB(pass / spp) (what global_render returned for
-// this pass), merged_rgb = sRGB(sum / count).  One wave per 32 pixels, spectra staged through LDS.
+// this pass), merged_rgb = sRGB(sum / count).  One wave per MERGE_PIXELS pixels, both spectra staged through LDS.
+// (32 pixels: every lane encodes one image of one pixel, and the 2 x 95 divisions per pixel are what the kernel's time
+// goes to beside its three HBM streams; with 16 pixels per wave - 13 resident workgroups per CU instead of 6, half the
+// lanes encoding - it ran at 0.92 ms per 1080p pass against 0.79.)
 constexpr int MERGE_PIXELS = 32;
 __global__ __launch_bounds__(64) void progressive_merge_kernel(const float *__restrict__ pass, int64_t n_pixels, float spp,
                                                               float *__restrict__ sum, float *__restrict__ count,
@@ -836,7 +846,7 @@ __global__ __launch_bounds__(64) void progressive_merge_kernel(const float *__re
     __shared__ __align__(16) float sp[MERGE_PIXELS * NBINS], sm[MERGE_PIXELS * NBINS];
     const int64_t first = (int64_t)blockIdx.x * MERGE_PIXELS;
     const int cnt = (int)((n_pixels - first < MERGE_PIXELS) ? (n_pixels - first) : MERGE_PIXELS);
-    // a block's 32 spectra are 12 160 contiguous bytes, 16-byte aligned when the planes are: 16-byte loads and stores
+    // a block's spectra are MERGE_PIXELS x 380 contiguous bytes, 16-byte aligned when the planes are: 16-byte loads and stores
     const float *src = pass + first * NBINS;
     float *dst = sum + first * NBINS;
     const int nf = cnt * NBINS, nv = nf / 4;
@@ -856,9 +866,9 @@ __global__ __launch_bounds__(64) void progressive_merge_kernel(const float *__re
         sm[i] = t;
     }
     __syncthreads();
-    // lanes 0..31 encode the pass image, lanes 32..63 the merged image of the same 32 pixels
+    // lanes 0 .. MERGE_PIXELS-1 encode the pass image, the next MERGE_PIXELS lanes the merged image of the same pixels
     const int lane = threadIdx.x & (MERGE_PIXELS - 1);
-    if (lane >= cnt) return;
+    if (lane >= cnt || threadIdx.x >= 2 * MERGE_PIXELS) return;
     const int64_t pix = first + lane;
     float out[3];
     if (threadIdx.x < MERGE_PIXELS) {
@@ -879,10 +889,10 @@ __global__ __launch_bounds__(64) void progressive_add_kernel(const float *__rest
                                                             float *__restrict__ sum, float *__restrict__ count,
                                                             float *__restrict__ merged_rgb)
 {
-    __shared__ float sp[64 * NBINS];
-    __shared__ int64_t pix_of[64];
-    const int64_t first = (int64_t)blockIdx.x * 64;
-    const int cnt = (int)((n - first < 64) ? (n - first) : 64);
+    __shared__ float sp[STAGE_PIXELS * NBINS];
+    __shared__ int64_t pix_of[STAGE_PIXELS];
+    const int64_t first = (int64_t)blockIdx.x * STAGE_PIXELS;
+    const int cnt = (int)((n - first < STAGE_PIXELS) ? (n - first) : STAGE_PIXELS);
     const int lane = threadIdx.x;
     if (lane < cnt) {
         const int x = px[first + lane], y = py[first + lane];
