@@ -48,11 +48,15 @@ FLOP_PER_BOX_TEST = 30.0    # 3d slab test of one box
 
 def profile_counters(tag):
     """Executed-instruction evidence for one configuration from the committed rocprofv3 PMC passes
-    (profiles/r*/pmc_<tag>.json, written by tools/collect_profiles.py from separate --pmc runs): the fraction of the
-    SIMDs' cycles in which a vector instruction was executing (SQ_ACTIVE_INST_VALU x 4 over GRBM_GUI_ACTIVE / 8 XCDs x
-    1024 SIMDs; the counter sums per-wave execution cycles, which overlap in the pipeline, so it can read slightly
-    above 1 on a saturated pipe) and the HBM bytes per launch (FETCH_SIZE doubled as gfx950 needs, + WRITE_SIZE).
-    These are replayed from the profile files, not measured in this run: `source` says which file."""
+    (profiles/r*/pmc_<tag>.json, written by tools/collect_profiles.py from separate --pmc runs):
+      valu_issue_frac       the share of the SIMDs' cycles in which a vector instruction was executing
+                            (SQ_ACTIVE_INST_VALU x 4 over GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs; the counter sums per-wave
+                            execution cycles, which overlap in the pipeline, so a saturated pipe reads 0.95 to 1.15);
+      hbm_bytes_per_launch  FETCH_SIZE doubled as gfx950 needs, + WRITE_SIZE;
+      flop_f32 / flop_f64   the hardware's own FLOP count by type (SQ_INSTS_VALU_FLOPS_FP32 / _FP64: per wave
+                            instruction, FMA = 2) x 64 lanes, and the share of lanes active while vector instructions ran.
+    These are replayed from the profile files, not measured in this run: `source` says which file, and `kernel_ms`
+    of the profiled launches turns the counts into rates."""
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", f"pmc_{tag}.json")))
     if not files:
         return None
@@ -65,27 +69,36 @@ def profile_counters(tag):
             out["valu_insts_per_launch"] = d["SQ_INSTS_VALU"]
         if "hbm_bytes_per_launch_corrected" in d:
             out["hbm_bytes_per_launch"] = d["hbm_bytes_per_launch_corrected"]
+        for k in ("flop_f32_per_launch_full_waves", "flop_f64_per_launch_full_waves", "valu_active_lane_share"):
+            if k in d:
+                out[k] = d[k]
         return out
     except Exception:
         return None
 
 
-def roofline(kind, st, kernel, n_prims, hbm_bytes_per_launch, tag):
+def roofline(kind, st, kernel, n_prims, hbm_model_bytes_per_launch, tag):
     """The roofline object of one measured configuration.  `st` = the context's counters over the timed launches.
 
-    achieved = the reference's algorithmic work per launch over the kernel's average launch duration (HIP events on the
-    launch stream, folded into rt_stats.kernel_ms): 2d and the 3d linear scan = rays x (FLOP per test x primitives + 60),
-    the work trace_ray does per invocation; 3d BVH = counted work (inner-node visits x 2 boxes x 30 + exact sphere
-    tests x 23 + 60 per ray).  It is an EQUIVALENT rate: the kernels decide most tests with a packed-f32 sign filter in
-    2.5 to 5 instruction slots and search the shared primary hit of a pair's lambda-samples once, so they execute fewer
-    operations than the model counts.  peak = the packed-f32 vector peak, the roofline BASELINE.json's metric names."""
+    frac (= achieved / peak) is an EQUIVALENT rate: the reference's algorithmic work per launch over the kernel's
+    average launch duration (HIP events on the launch stream, folded into rt_stats.kernel_ms): 2d and the 3d linear
+    scan = rays x (FLOP per test x primitives + 60), the work trace_ray does per invocation; 3d BVH = counted work
+    (inner-node visits x 2 boxes x 30 + exact sphere tests x 23 + 60 per ray).  The kernels decide most tests with a
+    packed-f32 sign filter in 2.5 to 5 instruction slots and search the shared primary hit of a pair's lambda-samples
+    once, so they execute fewer operations than the model counts.  peak = the packed-f32 vector peak, the roofline
+    BASELINE.json's metric names.  Beside it:
+      frac_searches_executed  the same model priced on the searches the kernel ran (2d), over the same peak;
+      valu_issue_frac         how busy the vector pipes were (PMC);
+      executed_f32 / _f64     the FLOP the hardware counted, by type, over the peak of that type (PMC);
+      hbm                     HBM bytes per launch from the PMC counters (or, for a workload nobody profiled, the
+                              algorithmic bytes of the accumulation atomics as a stand-in, labelled) over 8 TB/s."""
     launches = max(1, st["launches"])
     kernel_ms = st["kernel_ms"] / launches
     rays = st["rays"] / launches
-    executed = 0.0
+    searched = None
     if kind == "2d":
         flop = rays * (FLOP_PER_TEST_2D * n_prims + FLOP_PER_SHADE)
-        executed = (st["searches"] / launches) * FLOP_PER_TEST_2D * n_prims + rays * FLOP_PER_SHADE
+        searched = (st["searches"] / launches) * FLOP_PER_TEST_2D * n_prims + rays * FLOP_PER_SHADE
         model = f"rays x (15 x {n_prims} + 60) FLOP"
     elif kind == "3d_linear":
         flop = rays * (FLOP_PER_SPHERE_TEST * n_prims + FLOP_PER_SHADE)
@@ -97,16 +110,9 @@ def roofline(kind, st, kernel, n_prims, hbm_bytes_per_launch, tag):
     achieved = flop / sec / 1e12
     out = {"bound": "valu", "achieved": achieved, "peak": F32_PACKED_PEAK_TFLOPS, "unit": "TFLOP/s",
            "frac": achieved / F32_PACKED_PEAK_TFLOPS, "kind": "equivalent (reference work per launch / launch time)",
-           "kernel": kernel, "kernel_ms": kernel_ms, "flop_model": model, "traffic": None,
-           "hbm": {"achieved": hbm_bytes_per_launch / sec / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                   "frac": hbm_bytes_per_launch / sec / 1e9 / HBM_PEAK_GBS,
-                   "model": "read-modify-write of the accumulation buffer once per launch"}}
-    if kind == "2d":
-        # what the kernel itself did, in the same units: every search priced at 15 FLOP per primitive, every shade at 60,
-        # against the f64 vector peak (the exact tests and the shading are f64)
-        out["executed_work"] = {"achieved": executed / sec / 1e12, "peak": F64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                "frac": executed / sec / 1e12 / F64_VECTOR_PEAK_TFLOPS,
-                                "model": f"searches x 15 x {n_prims} + rays x 60 FLOP"}
+           "kernel": kernel, "kernel_ms": kernel_ms, "flop_model": model, "traffic": None}
+    if searched is not None:
+        out["frac_searches_executed"] = searched / sec / 1e12 / F32_PACKED_PEAK_TFLOPS
     if kind == "3d_bvh":
         # for comparison with the linear-scan line only: the work the reference's scan does for the same rays, over
         # this kernel's time.  The tree skips most of it, so this is no utilisation and can exceed any peak.
@@ -114,9 +120,26 @@ def roofline(kind, st, kernel, n_prims, hbm_bytes_per_launch, tag):
         out["reference_scan_equivalent"] = {"achieved": scan / sec / 1e12, "unit": "TFLOP/s",
                                             "model": f"rays x (23 x {n_prims} + 60) FLOP, the linear scan's work for the same rays; not a fraction of a peak"}
     prof = profile_counters(tag)
+    hbm_bytes, hbm_model = hbm_model_bytes_per_launch, "stand-in (no PMC profile of this workload): algorithmic bytes of the accumulation atomics and the shared primary hits"
     if prof:
-        out["traffic"] = prof.get("hbm_bytes_per_launch")
-        out["executed"] = prof
+        out["counters_from"] = prof["source"]
+        if "valu_issue_frac" in prof:
+            out["valu_issue_frac"] = prof["valu_issue_frac"]
+        if "valu_insts_per_launch" in prof:
+            out["valu_insts_per_ray"] = prof["valu_insts_per_launch"] * 64.0 / max(1.0, rays)
+        if "hbm_bytes_per_launch" in prof:
+            out["traffic"] = hbm_bytes = prof["hbm_bytes_per_launch"]
+            hbm_model = "PMC: 2 x FETCH_SIZE + WRITE_SIZE per launch, over this run's launch time"
+        for name, key, peak in (("executed_f32", "flop_f32_per_launch_full_waves", F32_PACKED_PEAK_TFLOPS),
+                                ("executed_f64", "flop_f64_per_launch_full_waves", F64_VECTOR_PEAK_TFLOPS)):
+            if key in prof:
+                rate = prof[key] / sec / 1e12
+                out[name] = {"achieved": rate, "peak": peak, "unit": "TFLOP/s", "frac": rate / peak,
+                             "model": "PMC: hardware FLOP count of this type per launch (per wave instruction, FMA = 2) x 64 lanes, over this run's launch time"}
+        if "valu_active_lane_share" in prof:
+            out["valu_active_lane_share"] = prof["valu_active_lane_share"]
+    out["hbm"] = {"achieved": hbm_bytes / sec / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                  "frac": hbm_bytes / sec / 1e9 / HBM_PEAK_GBS, "model": hbm_model}
     return out
 
 
@@ -154,8 +177,10 @@ class Work2D:
         self.xyz = None
         self.kernel = "render2d_kernel"
         self.tag = tag or f"{scene_name}_{W}x{H}_s{spp}_l{ls}"
-        self.hbm_bytes_per_launch = 2.0 * W * H * rt.NBINS * 4
         self.samples_per_pass = W * H * spp * ls
+        # algorithmic bytes when no counters exist for the workload: one 32-byte memory-side atomic per sample (an upper
+        # bound: samples that return 0 add nothing) + the 44 bytes a (pixel, sample) pair's shared primary hit takes
+        self.hbm_bytes_per_launch = 32.0 * self.samples_per_pass + 44.0 * W * H * spp
 
     def describe(self):
         return (f"2d {self.name} ({self.n_prims} primitives, seed 1) {self.W}x{self.H}, {self.spp} spp/pass, "
@@ -201,8 +226,10 @@ class Work3D:
         self.buf = torch.zeros(W * H * 3, dtype=torch.float32, device="cuda")
         self.kernel = "render3d_kernel<%s>" % ("true" if use_bvh else "false")
         self.tag = tag or f"3d_{'bvh' if use_bvh else 'linear'}_{W}x{H}_s{spp}"
-        self.hbm_bytes_per_launch = 2.0 * W * H * 3 * 4
         self.samples_per_pass = W * H * spp
+        # algorithmic bytes when no counters exist: the wave accumulators' flushes, 3 atomics of 32 bytes per pixel and
+        # work unit of 16 samples
+        self.hbm_bytes_per_launch = 96.0 * W * H * max(1.0, spp / 16.0)
 
     def describe(self):
         return (f"3d standalone scene ({self.n_prims} spheres) {self.W}x{self.H}, {self.spp} spp/pass, bounce limit {self.depth}, "

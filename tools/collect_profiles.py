@@ -29,10 +29,18 @@ for name in ("pmc_sq1", "pmc_sq2", "pmc_fetch", "pmc_write", "pmc_flop1", "pmc_f
             agg[r["Counter_Name"]] += float(r["Counter_Value"])
             disp.add(r["Dispatch_Id"])
     for c, v in agg.items():
-        out[c] = v / max(1, len(disp))
+        key = c + "@flop2" if (name == "pmc_flop2" and c == "SQ_ACTIVE_INST_VALU") else c  # same counter, other pass
+        out[key] = v / max(1, len(disp))
 if "FETCH_SIZE" in out and "WRITE_SIZE" in out:
     # FETCH_SIZE / WRITE_SIZE are in KiB; FETCH_SIZE reads half the bytes of a coalesced stream on gfx950
     out["hbm_bytes_per_launch_corrected"] = (2.0 * out["FETCH_SIZE"] + out["WRITE_SIZE"]) * 1024.0
+if "SQ_INSTS_VALU_FLOPS_FP32" in out:
+    # the FLOPS counters advance per WAVE instruction (FMA = 2, others 1; checked against ADD + MUL + 2 FMA + TRANS of
+    # the per-type counters): x 64 lanes = lane-FLOP at full wave width
+    out["flop_f32_per_launch_full_waves"] = 64.0 * out["SQ_INSTS_VALU_FLOPS_FP32"]
+    out["flop_f64_per_launch_full_waves"] = 64.0 * out["SQ_INSTS_VALU_FLOPS_FP64"]
+    if out.get("SQ_ACTIVE_INST_VALU@flop2"):
+        out["valu_active_lane_share"] = out["SQ_THREAD_CYCLES_VALU"] / (64.0 * out["SQ_ACTIVE_INST_VALU@flop2"])
 json.dump({"kernel": kernel, "per_dispatch": out}, open(os.path.join(dest, f"pmc_{tag}.json"), "w"), indent=1)
 print(open(stats).read())
 print(json.dumps(out, indent=1))
