@@ -42,6 +42,12 @@ extern "C" {
 
 #define RT_NBINS 95 /* SPECTRUM_SAMPLES, 2d/src/spectrum.rs:106 */
 
+/* The layout generation of the structs in this header.  A caller compiled against an older header passes structs of
+ * another size (rt_stats was 32 bytes in generation 1 and is 56 since generation 2; rt_ctx_get_stats writes all of
+ * it): compare rt_abi_version() with the RT_ABI_VERSION it was compiled with before the first call that takes a
+ * struct.  No counterpart in the reference, which has no binary boundary. */
+#define RT_ABI_VERSION 3
+
 enum {
     RT_OK = 0,
     RT_E_INVALID = -1,   /* bad argument / malformed scene */
@@ -140,6 +146,8 @@ typedef struct rt2d_scene rt2d_scene;
 typedef struct rt3d_scene rt3d_scene;
 
 /* ---- library / context --------------------------------------------------- */
+/* The library's RT_ABI_VERSION (see above): compare it with the one the caller was compiled with. */
+int32_t rt_abi_version(void);
 const char *rt_version(void);
 const char *rt_last_error(void);
 int32_t rt_device_count(int32_t *count);
@@ -325,7 +333,9 @@ int32_t rt2d_forward_render(rt_ctx *ctx, const rt2d_scene *scene, const rt2d_for
  * and never synchronises.  Limits: width * height <= 2^20 pixels (RT_E_LIMIT beyond; the reference draws 800 x 600).
  * d_lines (nullable) is DEVICE memory, one uint64: it receives the number of lines drawn, on the context's stream.
  * All calls on one GPU share that GPU's array: calls that overlap in time on one GPU (two contexts or two streams)
- * race; calls ordered on one stream do not.                                                                     */
+ * race; calls ordered on one stream do not.  In rt_stats such a call shows in `rays` and `samples` only: with no
+ * event it adds nothing to `kernel_ms` and `launches`, so rays / kernel_ms of a context that mixes the two forward
+ * entry points overstates the kernels' rate.                                                                    */
 int32_t rt2d_forward_accumulate_static(rt_ctx *ctx, const rt2d_scene *scene, const rt2d_forward_params *params,
                                        void *d_rgb, void *d_weight, void *d_lines);
 

@@ -69,8 +69,11 @@ class Stats(C.Structure):
                 ("bvh_node_visits", C.c_uint64), ("sphere_tests", C.c_uint64), ("searches", C.c_uint64)]
 
 
+ABI_VERSION = 3  # RT_ABI_VERSION of the include/rt_abi.h these bindings mirror
+
 # every symbol include/rt_abi.h declares: name -> (restype, argtypes)
 ABI = {
+    "rt_abi_version": (C.c_int32, []),
     "rt_version": (C.c_char_p, []),
     "rt_last_error": (C.c_char_p, []),
     "rt_device_count": (C.c_int32, [c_int32_p]),
@@ -159,6 +162,9 @@ def lib():
     if _lib is None:
         # RT_AMD_LIBNAME selects a diagnostic build of the same HIP library (e.g. the -DRT_PROF one)
         _lib = _load(os.environ.get("RT_AMD_LIBNAME", "librt_amd.so"), ABI)
+        if _lib.rt_abi_version() != ABI_VERSION:  # the ctypes structs below mirror ONE generation of include/rt_abi.h
+            got, _lib = _lib.rt_abi_version(), None
+            raise RuntimeError(f"librt_amd.so has struct layout generation {got}, this binding was written for {ABI_VERSION}")
     return _lib
 
 

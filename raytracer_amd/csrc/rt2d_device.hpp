@@ -430,6 +430,10 @@ RT_DEV Hit nearest_hit(SceneK S, double ox, double oy, double dx, double dy, boo
         }
 #endif
         const uint64_t fresh = __ballot(mw != 0u);
+#ifdef RT_PROF
+        prof.t[16] += (unsigned long long)__popcll(fresh);
+        prof.t[17] += (unsigned long long)__popcll(__ballot((mw & (mw - 1u)) != 0u));
+#endif
         if (fresh != 0) {
             if (mw != 0u) {
                 const int at = (head + count + rank_in_mask(fresh)) & 127;

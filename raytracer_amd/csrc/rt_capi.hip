@@ -216,7 +216,8 @@ struct Carver {
 
 extern "C" {
 
-const char *rt_version(void) { return "raytracer_amd 0.1 (gfx950)"; }
+const char *rt_version(void) { return "raytracer_amd 0.3 (gfx950)"; }
+int32_t rt_abi_version(void) { return RT_ABI_VERSION; }
 
 const char *rt_last_error(void) { return g_err.c_str(); }
 
@@ -674,8 +675,8 @@ int32_t launch_render2d(rt_ctx *ctx, const rt2d_scene *scene, const rt2d_render_
 #ifdef RT_PROF
     {
         static unsigned long long *d_prof = nullptr;
-        if (!d_prof) { HIP_TRY(hipMalloc((void **)&d_prof, 16 * sizeof(unsigned long long))); }
-        HIP_TRY(hipMemsetAsync(d_prof, 0, 16 * sizeof(unsigned long long), ctx->stream));
+        if (!d_prof) { HIP_TRY(hipMalloc((void **)&d_prof, 20 * sizeof(unsigned long long))); }
+        HIP_TRY(hipMemsetAsync(d_prof, 0, 20 * sizeof(unsigned long long), ctx->stream));
         A.prof_out = d_prof;
     }
 #endif
@@ -758,10 +759,13 @@ int32_t launch_render2d(rt_ctx *ctx, const rt2d_scene *scene, const rt2d_render_
     ctx->launches += 1;
 #ifdef RT_PROF
     {
-        unsigned long long h[16];
+        unsigned long long h[20];
         HIP_TRY(hipStreamSynchronize(ctx->stream));
         HIP_TRY(hipMemcpy(h, A.prof_out, sizeof h, hipMemcpyDeviceToHost));
         const double tot = (double)(h[0] + h[1] + h[2] + h[3] + h[4] + h[7] + h[8] + h[9] + h[12] + h[13]);
+        if (h[16])
+            fprintf(stderr, "[rt_prof] candidate-queue entries per wave-step %.1f, of which with more than one slot %.3f\n",
+                    (double)h[16] / (double)h[5], (double)h[17] / (double)h[16]);
         fprintf(stderr, "[rt_prof] candidates per wave-step %.1f, phase-2 rounds per wave-step %.2f, hemisphere rounds per wave-step %.2f for %.1f lanes\n",
                 (double)h[10] / (double)h[5], (double)h[11] / (double)h[5], (double)h[14] / (double)h[5], (double)h[15] / (double)h[5]);
         fprintf(stderr, "[rt_prof] regen %.3f phase1 %.3f phase2 %.3f classify %.3f normal %.3f bend %.3f shade-rest %.3f hemisphere %.3f tail %.3f loop %.3f | wave_steps %llu lanes/step %.2f cycles/step %.0f\n",

@@ -126,7 +126,7 @@ RT_DEV double rlen3(double x, double y, double z) { return 1.0 / __builtin_sqrt(
 // sections, stamped with s_memtime.  Never compiled into the shipped library.
 #ifdef RT_PROF
 struct Prof {
-    unsigned long long t[16];
+    unsigned long long t[20];
     unsigned long long last;
 };
 #define RT_STAMP(prof, i)                                                              \

@@ -307,7 +307,7 @@ __global__ __launch_bounds__(BLOCK, (SMALL || NOSEG) ? 7 : 6) void render2d_kern
     }
 #ifdef RT_PROF
     if (lane == 0 && Ak->prof_out)
-        for (int i = 0; i < 16; ++i) atomicAdd(Ak->prof_out + i, prof.t[i]);
+        for (int i = 0; i < 20; ++i) atomicAdd(Ak->prof_out + i, prof.t[i]);
 #endif
 
     // rays traced by this wave, and how many of them skipped the search -> one global atomic each
@@ -1130,7 +1130,7 @@ __global__ __launch_bounds__(BLOCK, 5) void render3d_kernel(const Render3dArgs A
     }
 #ifdef RT_PROF
     if (lane == 0 && Ak->prof_out)
-        for (int i = 0; i < 16; ++i) atomicAdd(Ak->prof_out + i, prof.t[i]);
+        for (int i = 0; i < 20; ++i) atomicAdd(Ak->prof_out + i, prof.t[i]);
 #endif
     // the last unit's accumulator was flushed when the wave found no further unit
     for (int off = 32; off > 0; off >>= 1) {

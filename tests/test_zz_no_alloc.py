@@ -59,3 +59,47 @@ def test_static_entry_point_rejects_what_its_scratch_cannot_hold(gpu_ctx):
         scene.forward_accumulate_static(p, buf.data_ptr(), buf.data_ptr() + 4 * 3 * 1025 * 1024)
     assert e.value.code == -5 and "static scratch" in str(e.value)   # RT_E_LIMIT
     scene.close()
+
+
+def test_static_entry_point_allocates_nothing_and_can_be_captured(gpu_ctx):
+    """The contract beyond the result: no device allocation (free memory is the same before and after a call), and no
+    event, allocation or synchronisation on the way - so the call can be recorded into a HIP graph, where any of those
+    fails the capture, and the replayed graph adds what the eager call adds."""
+    W, H = 400, 300
+    scene = rt.Scene2D(gpu_ctx, rt.World2D("complex_world", seed=1))
+    p = scene.forward_params(W, H, 500, 5, seed=3)
+    side = torch.cuda.Stream()
+    gpu_ctx.set_stream(side.cuda_stream)
+    try:
+        eager = torch.zeros(W * H * 4, device="cuda")
+        replayed = torch.zeros(W * H * 4, device="cuda")
+        d_lines = torch.zeros(1, dtype=torch.int64, device="cuda")
+        torch.cuda.synchronize()
+        scene.forward_accumulate_static(p, eager.data_ptr(), eager.data_ptr() + 4 * 3 * W * H, d_lines.data_ptr())   # warm-up: module load
+        gpu_ctx.synchronize()
+        eager.zero_()
+        torch.cuda.synchronize()
+        free_before = torch.cuda.mem_get_info()[0]
+        scene.forward_accumulate_static(p, eager.data_ptr(), eager.data_ptr() + 4 * 3 * W * H, d_lines.data_ptr())
+        gpu_ctx.synchronize()
+        assert torch.cuda.mem_get_info()[0] == free_before
+        lines_eager = int(d_lines.item())
+        assert lines_eager > 0
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            scene.forward_accumulate_static(p, replayed.data_ptr(), replayed.data_ptr() + 4 * 3 * W * H, d_lines.data_ptr())
+        torch.cuda.synchronize()
+        assert not replayed.any()                       # recording runs nothing
+        d_lines.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert int(d_lines.item()) == lines_eager
+        a, b = eager.cpu().numpy(), replayed.cpu().numpy()
+        assert np.array_equal(np.rint(a[3 * W * H:]), np.rint(b[3 * W * H:]))          # items per pixel
+        assert np.allclose(a, b, rtol=1e-5, atol=1e-5)
+        graph.replay()                                  # a second replay adds the same again
+        torch.cuda.synchronize()
+        assert np.allclose(replayed.cpu().numpy(), 2.0 * a, rtol=1e-5, atol=1e-5)
+    finally:
+        gpu_ctx.set_stream(None)
+        scene.close()
