@@ -364,7 +364,15 @@ def main():
     backend = os.environ.get("RT_BENCH_BACKEND", "nccl")
     device = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
     torch.cuda.set_device(device)
-    if world_size > 1:
+    # RT_BENCH_FORCE_DIST=1 takes the N > 1 road with one rank too: the process group is created and the merge step
+    # goes through its all-reduce (RCCL with backend nccl), which a one-GPU box can then exercise
+    use_dist = world_size > 1 or bool(os.environ.get("RT_BENCH_FORCE_DIST"))
+    if use_dist:
+        if world_size == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", device))
         else:
@@ -387,7 +395,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world_size > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -403,7 +411,7 @@ def main():
         work = Work3D(rt, torch, ctx, args.width, args.height, args.spp, args.depth, bool(args.bvh))
     else:
         work = Work2D(rt, torch, ctx, args.scene, args.width, args.height, args.spp, args.lambda_samples, args.depth, merge=args.merge)
-    merge_fn = reduce_sum if world_size > 1 else None
+    merge_fn = reduce_sum if use_dist else None
 
     if strong:
         lo, hi = strong_range(rank, world_size, args.total_spp)
@@ -435,7 +443,7 @@ def main():
             work.finish(total_spp(n_steps, world_size, work.spp), merge_fn)
         warm = lambda: run(args.warmup)  # noqa: E731
 
-    if world_size > 1:
+    if use_dist:
         # communicator set-up (the first collective of a process group builds its rings) stays outside the timed job
         # whatever --warmup says: one reduction of the size the job's merge moves
         n_merge = work.W * work.H * 3 if (work.kind != "2d" or args.merge == "xyz") else work.W * work.H * rt.NBINS
@@ -461,10 +469,10 @@ def main():
     st = ctx.stats()
     t = torch.tensor([dt], dtype=torch.float64, device="cuda")
     counts = torch.tensor([st["rays"], st["samples"], st["searches"]], dtype=torch.float64, device="cuda")
-    if world_size > 1 and backend == "nccl":
+    if use_dist and backend == "nccl":
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(counts, op=dist.ReduceOp.SUM)
-    elif world_size > 1:
+    elif use_dist:
         t, counts = t.cpu(), counts.cpu()
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(counts, op=dist.ReduceOp.SUM)
@@ -472,7 +480,7 @@ def main():
     total_rays, total_samples, total_searches = (float(c) for c in counts.tolist())
 
     if rank == 0:
-        if world_size == 1:
+        if not use_dist:
             merge = "resolve" if work.kind == "2d" else "no merge step"
         elif work.kind != "2d":
             merge = "all-reduce of the f32[W*H][3] image"
@@ -485,7 +493,7 @@ def main():
             workload = f"{work.describe()}; job = {args.steps} steps + {merge}"
         out = {
             "metric": "Mrays/s", "value": total_rays / dt / 1e6, "unit": "Mrays/s",
-            "n_gpus": world_size, "ranks": dist.get_world_size() if world_size > 1 else 1, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": world_size, "ranks": dist.get_world_size() if use_dist else 1, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if strong else "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": workload, "parallelism": f"sample-batch x{world_size}",
@@ -522,7 +530,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(rt.World2D(args.scene, seed=1), p_full, threads, args.cpu_spp)
         print(json.dumps(out), flush=True)
 
-    if world_size > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -368,6 +368,8 @@ public:
 
     ReverseRenderer(const ReverseRenderParams &p, int device = 0) : render_params(p)
     {
+        // the structs this file passes were laid out by the include/rt_abi.h it was compiled with
+        if (rt_abi_version() != RT_ABI_VERSION) throw RtError("librt_amd.so was built from another generation of include/rt_abi.h");
         check(rt_ctx_create(device, &ctx_));
     }
     ~ReverseRenderer()
@@ -594,6 +596,8 @@ public:
 
     explicit ForwardRenderer(const ForwardRenderParams &p, int device = 0) : render_params_(p)
     {
+        // the structs this file passes were laid out by the include/rt_abi.h it was compiled with
+        if (rt_abi_version() != RT_ABI_VERSION) throw RtError("librt_amd.so was built from another generation of include/rt_abi.h");
         check(rt_ctx_create(device, &ctx_));
     }
     ~ForwardRenderer()

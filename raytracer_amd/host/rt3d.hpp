@@ -46,6 +46,8 @@ public:
     World(const Camera &camera, const std::vector<Sphere> &objects, const RenderParams &params, int device = 0)
         : camera_(camera), params_(params)
     {
+        // the structs this file passes were laid out by the include/rt_abi.h it was compiled with
+        if (rt_abi_version() != RT_ABI_VERSION) throw RtError("librt_amd.so was built from another generation of include/rt_abi.h");
         check(rt_ctx_create(device, &ctx_));
         std::vector<double> cx, cy, cz, r;
         for (const Sphere &s : objects) { cx.push_back(s.center.x); cy.push_back(s.center.y); cz.push_back(s.center.z); r.push_back(s.radius); }

@@ -36,3 +36,21 @@ def test_plain_invocation_spawns_its_ranks(gpu_ctx):
 def test_plain_invocation_strong_mode(gpu_ctx):
     out = _run(["--mode", "strong", "--workload", "3d", "--total-spp", "6", "--steps", "1"])
     assert out["n_gpus"] == 2 and out["ranks"] == 2 and out["scaling"] == "strong"
+
+
+@pytest.mark.parametrize("extra,merge_text", [(["--width", "320", "--height", "180", "--spp", "8"], "XYZ projection + all-reduce + encode"),
+                                              (["--width", "320", "--height", "180", "--spp", "8", "--merge", "spectral"], "spectral all-reduce + resolve"),
+                                              (["--mode", "strong", "--workload", "3d", "--total-spp", "6", "--steps", "1"], "all-reduce of the f32[W*H][3] image")])
+def test_the_merge_runs_over_rccl_with_one_rank(extra, merge_text, gpu_ctx):
+    """The N > 1 road of bench.py with backend nccl (= RCCL) on the one GPU of the box: RT_BENCH_FORCE_DIST=1 creates
+    the process group and sends the merge step through its all-reduce although there is one rank.  What a node adds
+    is more ranks, not other code: device tensors on torch's stream, ordered behind the render kernels."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "RT_BENCH_BACKEND")}
+    env["RT_BENCH_FORCE_DIST"] = "1"
+    env["RT_BENCH_WATCHDOG"] = "240"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+                        "--configs", "none", "--cpu-spp", "0"] + extra, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert out["n_gpus"] == 1 and out["ranks"] == 1 and merge_text in out["config"]["workload"]
+    assert out["value"] > 0
