@@ -1412,7 +1412,7 @@ struct BuildSphere { double c[3], r; int sid; };
 
 // BVH over sphere boxes; children of a node are adjacent; leaves hold <= rt3d::LEAF_MAX spheres.
 struct BvhBuilder {
-    static constexpr int SWEEP_MAX = 4096; // nodes up to this size are split by the surface-area heuristic
+    static constexpr int SWEEP_MAX = 4096; // nodes up to this size are split by the surface-area heuristic's full sweep
     struct Box {
         double lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
         void add(const BuildSphere &s)
@@ -1479,12 +1479,57 @@ struct BvhBuilder {
             }
             if (axis != 2) std::sort(sp.begin() + first, sp.begin() + first + count, by_axis(axis));
         } else {
-            // large nodes: median of the widest centre extent
+            // large nodes: the same heuristic over 32 bins of the centre coordinate per axis (a full sweep sorts the
+            // node three times), the median of the widest centre extent when no bin boundary separates anything
             double clo[3] = { INFINITY, INFINITY, INFINITY }, chi[3] = { -INFINITY, -INFINITY, -INFINITY };
             for (int i = first; i < first + count; ++i)
                 for (int a = 0; a < 3; ++a) { clo[a] = std::min(clo[a], sp[(size_t)i].c[a]); chi[a] = std::max(chi[a], sp[(size_t)i].c[a]); }
-            for (int a = 1; a < 3; ++a) if (chi[a] - clo[a] > chi[axis] - clo[axis]) axis = a;
-            std::nth_element(sp.begin() + first, sp.begin() + mid, sp.begin() + first + count, by_axis(axis));
+            constexpr int BINS = 32;
+            double best = INFINITY;
+            int best_axis = -1, kcut = 0;
+            if (!median_only)
+                for (int a = 0; a < 3; ++a) {
+                    const double ext = chi[a] - clo[a];
+                    if (!(ext > 0.0)) continue;
+                    Box bin_box[BINS];
+                    int bin_n[BINS] = { 0 };
+                    auto bin_of = [&](const BuildSphere &b) { return std::min(BINS - 1, (int)((b.c[a] - clo[a]) / ext * BINS)); };
+                    for (int i = first; i < first + count; ++i) { const int k = bin_of(sp[(size_t)i]); bin_box[k].add(sp[(size_t)i]); bin_n[k] += 1; }
+                    double right_area[BINS];
+                    int right_n[BINS];
+                    Box r;
+                    int rn = 0;
+                    for (int k = BINS - 1; k > 0; --k) {
+                        if (bin_n[k]) { for (int c = 0; c < 3; ++c) { r.lo[c] = std::min(r.lo[c], bin_box[k].lo[c]); r.hi[c] = std::max(r.hi[c], bin_box[k].hi[c]); } }
+                        rn += bin_n[k];
+                        right_area[k] = rn ? r.half_area() : 0.0;
+                        right_n[k] = rn;
+                    }
+                    Box l;
+                    int ln = 0;
+                    for (int k = 1; k < BINS; ++k) { // split between bins k - 1 and k
+                        if (bin_n[k - 1]) { for (int c = 0; c < 3; ++c) { l.lo[c] = std::min(l.lo[c], bin_box[k - 1].lo[c]); l.hi[c] = std::max(l.hi[c], bin_box[k - 1].hi[c]); } }
+                        ln += bin_n[k - 1];
+                        if (ln == 0 || right_n[k] == 0) continue;
+                        const double cost = l.half_area() * ln + right_area[k] * right_n[k];
+                        if (cost < best) { best = cost; best_axis = a; kcut = k; }
+                    }
+                }
+            if (best_axis >= 0) {
+                axis = best_axis;
+                const int a = axis;
+                const double ext = chi[a] - clo[a], lo_a = clo[a];
+                auto it = std::partition(sp.begin() + first, sp.begin() + first + count, [&](const BuildSphere &b) {
+                    return std::min(BINS - 1, (int)((b.c[a] - lo_a) / ext * BINS)) < kcut;
+                });
+                mid = (int)(it - sp.begin());
+            }
+            if (best_axis < 0 || mid == first || mid == first + count) {
+                axis = 0;
+                mid = first + count / 2;
+                for (int a = 1; a < 3; ++a) if (chi[a] - clo[a] > chi[axis] - clo[axis]) axis = a;
+                std::nth_element(sp.begin() + first, sp.begin() + mid, sp.begin() + first + count, by_axis(axis));
+            }
         }
         const int left = (int)nodes.size();
         nodes.emplace_back();

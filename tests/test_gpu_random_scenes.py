@@ -227,9 +227,9 @@ def timed_grays(ctx, scene, spp=16):
 
 
 @pytest.mark.parametrize("n", [5_000, 20_000])
-def test_large_scenes_take_the_median_split_path(n, gpu_ctx, oracle, capsys):
-    """Scenes above the 4096 spheres up to which a node is split by the surface-area sweep: the top of the tree is
-    split at the median.  The BVH must return the linear scan's hits bit for bit (both on the GPU, 40 k rays), and both
+def test_large_scenes_split_by_binned_areas(n, gpu_ctx, oracle, capsys):
+    """Scenes above the 4096 spheres up to which a node is split by the full surface-area sweep: the top of the tree is
+    split over binned areas.  The BVH must return the linear scan's hits bit for bit (both on the GPU, 40 k rays), and both
     the checker's on a part of the rays; the two kernels' rates at this size are printed for the record."""
     rng = np.random.default_rng(n)
     c = rng.uniform(-20.0, 20.0, (n, 3))
