@@ -25,5 +25,6 @@ ctx.reset_stats()
 scene.accumulate(params3d(args.spp, 10, seed=0), buf.data_ptr())
 st = ctx.stats()
 print(json.dumps({"bvh": not args.linear, "kernel_ms": st["kernel_ms"], "rays": st["rays"],
-                  "Mrays_per_s": st["rays"] / st["kernel_ms"] / 1e3}))
+                  "Mrays_per_s": st["rays"] / st["kernel_ms"] / 1e3,
+                  "node_visits_per_ray": st["bvh_node_visits"] / st["rays"], "sphere_tests_per_ray": st["sphere_tests"] / st["rays"]}))
 scene.close()
