@@ -379,9 +379,6 @@ RT_DEV Hit no_hit()
     return best;
 }
 
-// Key of a hit record in f64::total_cmp order (rt.rs:224); the largest key while there is none.
-RT_DEV int64_t hit_key(const Hit &h) { return h.slot >= 0 ? total_key(h.t) : 0x7fffffffffffffffLL; }
-
 // A hit as an f32 at or above it: a box whose interval starts beyond THAT starts beyond the hit (equal t may
 // still win on index, so only strictly later boxes are dropped); +inf while there is no hit.
 RT_DEV float hit_bound(const Hit &best)
@@ -404,22 +401,6 @@ RT_DEV void always_hits(SceneK S, double ox, double oy, double oz, double dx, do
     } else {
         scan_range<false>(S, 0, S->n_always, ox, oy, oz, dx, dy, dz, active, best, best_key, work);
     }
-}
-
-// Does the ray reach either child box of the root before the hit it already has?  (The root's own visit, with the
-// node read as scalar operands: it is the same for every lane.)  A ray that does not is finished with the tree.
-typedef const BvhNode2 __attribute__((address_space(4))) *K_BvhNode2;
-RT_DEV bool enters_tree(SceneK S, const BoxRay &br, const Hit &best, Work &work)
-{
-    work.node_visits += 1; // counted again when the walk starts at the root: both are executed
-    const K_BvhNode2 root = (K_BvhNode2)S->nodes;
-    BvhNode2 nd;
-#pragma unroll
-    for (int i = 0; i < 6; ++i) nd.plane[i] = root->plane[i];
-    f32x2 tn;
-    bool h[2];
-    box_intervals(nd, br, hit_bound(best), tn, h);
-    return h[0] || h[1];
 }
 
 constexpr int BVH_STACK = 32;
