@@ -163,6 +163,12 @@ int32_t rt_ctx_synchronize(rt_ctx *ctx);
 /* Both synchronize the stream first. */
 int32_t rt_ctx_get_stats(rt_ctx *ctx, rt_stats *out);
 int32_t rt_ctx_reset_stats(rt_ctx *ctx);
+/* Self-check, no counterpart in the reference: the kernels compute sqrt(x) and 1 / sqrt(x) (glam's `normalize`,
+ * the discriminants of Circle::hit and Sphere::hit) with their own instruction sequences, shorter than the compiler's
+ * generic ones.  This runs both forms on the GPU over 2^log2_n arguments of each of five classes (the tracer's range,
+ * random bit patterns with every special value, significands of mostly ones or zeros, exact squares and neighbours,
+ * square roots next to a power of two) and returns how many results differ in any bit: all five must be 0. */
+int32_t rt_selftest_math(rt_ctx *ctx, int32_t log2_n, uint64_t seed, uint64_t *out_mismatches); /* [5] */
 
 /* ---- 2d: scene ----------------------------------------------------------- */
 /* Replaces borrowing `&World` (librt2d_reverse.rs:82,114): the arrays are copied. */

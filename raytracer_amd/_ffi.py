@@ -83,6 +83,7 @@ ABI = {
     "rt_ctx_use_own_stream": (C.c_int32, [C.c_void_p]),
     "rt_ctx_synchronize": (C.c_int32, [C.c_void_p]),
     "rt_ctx_get_stats": (C.c_int32, [C.c_void_p, C.POINTER(Stats)]),
+    "rt_selftest_math": (C.c_int32, [C.c_void_p, C.c_int32, C.c_uint64, C.POINTER(C.c_uint64)]),
     "rt_ctx_reset_stats": (C.c_int32, [C.c_void_p]),
     "rt2d_scene_create": (C.c_int32, [C.c_void_p, C.POINTER(Scene2DDesc), C.POINTER(C.c_void_p)]),
     "rt2d_scene_destroy": (C.c_int32, [C.c_void_p]),

@@ -218,6 +218,12 @@ class Context:
     def reset_stats(self):
         check(_ffi.lib().rt_ctx_reset_stats(self._ctx))
 
+    def selftest_math(self, log2_n=24, seed=0x1234):
+        """Mismatches per argument class between the kernels' own sqrt / reciprocal-sqrt sequences and the IEEE ones."""
+        out = (C.c_uint64 * 5)()
+        check(_ffi.lib().rt_selftest_math(self._ctx, int(log2_n), int(seed), out))
+        return [int(v) for v in out]
+
     def tonemap_reinhard(self, rgb, param=1.0, alpha=255):
         rgb = np.ascontiguousarray(rgb, np.float32).reshape(-1, 3)
         out = np.empty((rgb.shape[0], 4), np.uint8)

@@ -109,7 +109,7 @@ RT_DEV bool circle_t(double ox, double oy, double dx, double dy, double cx, doub
     const double c = (ocx * ocx + ocy * ocy) - r2;
     const double delta = b * b - 4.0 * a * c;
     if (delta < 0.0) return false;
-    const double sq = __builtin_sqrt(delta);
+    const double sq = sqrt_exact(delta);
     const double t0 = (-b - sq) / (2.0 * a);
     const double t1 = (-b + sq) / (2.0 * a);
     if (t0 > 0.0) { t = t0; return true; }
@@ -618,7 +618,7 @@ RT_DEV ShadeResult shade(SceneK S, Path &p, const Hit &h, float &value, double &
                                        : (outside ? S->inv_ior[m.ior_row * NBINS + p.li] : S->ior[m.ior_row * NBINS + p.li]);
             const double kk = 1.0 - eta * eta * (1.0 - ndi * ndi);
             if (kk >= 0.0) {
-                const double mm = eta * ndi + __builtin_sqrt(kk);
+                const double mm = eta * ndi + sqrt_exact(kk);
                 rx = eta * p.dx - mm * Nx;
                 ry = eta * p.dy - mm * Ny;
                 bounce = (rx == 0.0 && ry == 0.0); // `refracted_ray == DVec2::ZERO`
@@ -709,7 +709,7 @@ RT_DEV void rand_hemisphere_wave(bool need, double nx, double ny, uint32_t c0, u
             if (__builtin_fabs(du) > 0x1.0p-40 * (__builtin_fabs(a) + __builtin_fabs(b))) {
                 ok = du > 0.0;
             } else {
-                const double rl = 1.0 / __builtin_sqrt(l2);
+                const double rl = rsqrt_exact(l2);
                 ok = (vx * rl) * tnx + (vy * rl) * tny > 0.0;
             }
         }
@@ -729,7 +729,7 @@ RT_DEV void rand_hemisphere_wave(bool need, double nx, double ny, uint32_t c0, u
         pending = __ballot(still);
     }
     if (need) {
-        const double rl = 1.0 / __builtin_sqrt(ol2);
+        const double rl = rsqrt_exact(ol2);
         rx = ovx * rl;
         ry = ovy * rl;
     }

@@ -111,9 +111,10 @@ RT_DEV bool sphere_t(double ox, double oy, double oz, double dx, double dy, doub
     const double c = ((ocx * ocx + ocy * ocy) + ocz * ocz) - r2;
     const double delta = h * h - a * c;
     if (delta < 0.0) return false;
-    const double t0 = (h - __builtin_sqrt(delta)) / a;
+    const double sq = sqrt_exact(delta);
+    const double t0 = (h - sq) / a;
     if (t0 >= 0.0) { t = t0; return true; }
-    const double t1 = (h + __builtin_sqrt(delta)) / a;
+    const double t1 = (h + sq) / a;
     if (t1 >= 0.0) { t = t1; return true; }
     return false;
 }

@@ -1883,6 +1883,27 @@ int32_t rt3d_trace_batch(rt_ctx *ctx, const rt3d_scene *scene, int64_t n, const 
     return RT_OK;
 }
 
+int32_t rt_selftest_math(rt_ctx *ctx, int32_t log2_n, uint64_t seed, uint64_t *out_mismatches)
+{
+    if (int32_t rc = ctx_bind(ctx)) return rc;
+    if (!out_mismatches) return fail(RT_E_INVALID, "null out_mismatches");
+    if (log2_n < 0 || log2_n > 34) return fail(RT_E_LIMIT, "log2_n must be in 0..34");
+    void *ws = nullptr;
+    if (int32_t rc = ctx_workspace(ctx, 256, &ws)) return rc;
+    unsigned long long *d_bad = (unsigned long long *)ws;
+    HIP_TRY(hipMemsetAsync(d_bad, 0, 5 * sizeof(unsigned long long), ctx->stream));
+    for (int cls = 0; cls < 5; ++cls) {
+        hipLaunchKernelGGL(rtk::math_check_kernel, dim3(256 * 32), dim3(rtk::BLOCK), 0, ctx->stream, cls, (uint64_t)1 << log2_n,
+                           (uint32_t)seed + (uint32_t)cls, d_bad);
+        HIP_TRY(hipGetLastError());
+    }
+    unsigned long long h[5];
+    HIP_TRY(hipMemcpyAsync(h, d_bad, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < 5; ++i) out_mismatches[i] = h[i];
+    return RT_OK;
+}
+
 int32_t rt_tonemap_reinhard(rt_ctx *ctx, const float *rgb, int64_t n_pixels, float param, uint8_t alpha, uint8_t *out_rgba8)
 {
     if (int32_t rc = ctx_bind(ctx)) return rc;

@@ -118,9 +118,69 @@ RT_DEV int64_t total_key(double t)
 
 RT_DEV int hi32(double x) { return __double2hiint(x); }
 
+// fl(1 / fl(sqrt(x))): the two IEEE operations behind glam's `normalize` (v * length().recip()), bit for bit, in 16
+// instructions where the compiler's generic expansions of sqrt and of the division take 30.
+//   s:  the compiler's own square-root sequence (v_rsq_f64, one coupled refinement of g ~ sqrt(x) and h ~ 1 / (2 sqrt(x)),
+//       two residual corrections) without the scaling it wraps around it for arguments near the ends of the exponent
+//       range - for x in [2^-500, 2^500] nothing here comes near them, and the scaling is by powers of two, so s has
+//       the bits the generic form produces.
+//   1 / s: y = 2 h is already 1 / s to about 2^-49; y <- y + y (1 - s y) once brings it within half a unit in the last
+//       place (+ 2^-98 relative), and once more gives the correctly rounded reciprocal.  Why: scale s into [1, 2) and
+//       y into (1/2, 1]; with |y - 1/s| <= 2^-54 (1 + 2^-43) the residual e = 1 - s y is a multiple of 2^-105 below
+//       2^-53 in size, so the fused step forms it exactly, and the value rounded by the last step is (1/s)(1 - e^2).
+//       1/s = 2^52 / S (S the integer significand) lies at least 1 / (S 2^54) from every midpoint (2K + 1) 2^-54 of two
+//       neighbouring doubles, because 2^106 - (2K + 1) S is a non-zero integer; (1/s) e^2 <= (2^52 / S) s^2 2^-108
+//       (1 + 2^-43) stays below that distance whenever s^2 (1 + 2^-43) < 4: for every s but the few next to 2.  Those
+//       (the top 20 fraction bits all ones: one value in a million) and arguments outside [2^-500, 2^500] - zero,
+//       infinities and NaN among them - take the generic operations.
+// tools/ubench/rsqrt_check.hip compares this and sqrt_exact below with the generic operations on the GPU, bit for bit,
+// on five classes of arguments (random in the tracer's range, random bits incl. all specials, significands of mostly
+// ones or zeros, exact squares and their neighbours, square roots next to 2); tests/test_gpu_math.py runs it.
+RT_DEV double rsqrt_exact(double x)
+{
+    const double y0 = __builtin_amdgcn_rsq(x);
+    double g = x * y0, h = 0.5 * y0;
+    const double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    h = __builtin_fma(h, r, h);
+    double d = __builtin_fma(-g, g, x);
+    g = __builtin_fma(d, h, g);
+    d = __builtin_fma(-g, g, x);
+    const double s = __builtin_fma(d, h, g);
+    double y = h + h;
+    double e = __builtin_fma(-s, y, 1.0);
+    y = __builtin_fma(e, y, y);
+    e = __builtin_fma(-s, y, 1.0);
+    y = __builtin_fma(e, y, y);
+    // x in [2^-500, 2^500): one unsigned comparison on its high word (sign and exponent; NaN, infinities, zero,
+    // denormals and negatives all fall outside); the top 20 fraction bits of s not all ones: another
+    const bool plain = (uint32_t)__double2hiint(x) - 0x20B00000u < 0x5F400000u - 0x20B00000u &&
+                       ((uint32_t)__double2hiint(s) & 0xFFFFFu) != 0xFFFFFu;
+    if (__builtin_expect(!plain, 0)) y = 1.0 / __builtin_sqrt(x);
+    return y;
+}
+
+// fl(sqrt(x)) alone, for the discriminants of the exact hit tests: the same sequence without the compiler's scaling
+// (10 instructions against 17); arguments outside [2^-500, 2^500) - zero among them - take the generic operation.
+RT_DEV double sqrt_exact(double x)
+{
+    const double y0 = __builtin_amdgcn_rsq(x);
+    double g = x * y0, h = 0.5 * y0;
+    const double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    h = __builtin_fma(h, r, h);
+    double d = __builtin_fma(-g, g, x);
+    g = __builtin_fma(d, h, g);
+    d = __builtin_fma(-g, g, x);
+    double s = __builtin_fma(d, h, g);
+    const bool plain = (uint32_t)__double2hiint(x) - 0x20B00000u < 0x5F400000u - 0x20B00000u;
+    if (__builtin_expect(!plain, 0)) s = __builtin_sqrt(x);
+    return s;
+}
+
 // 1/len with len = sqrt(x.x + y.y): glam's normalize multiplies by the reciprocal.
-RT_DEV double rlen2(double x, double y) { return 1.0 / __builtin_sqrt(x * x + y * y); }
-RT_DEV double rlen3(double x, double y, double z) { return 1.0 / __builtin_sqrt((x * x + y * y) + z * z); }
+RT_DEV double rlen2(double x, double y) { return rsqrt_exact(x * x + y * y); }
+RT_DEV double rlen3(double x, double y, double z) { return rsqrt_exact((x * x + y * y) + z * z); }
 
 // Diagnostic build only (-DRT_PROF): per-wave cycle shares of the trace loop's
 // sections, stamped with s_memtime.  Never compiled into the shipped library.

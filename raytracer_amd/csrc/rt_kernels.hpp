@@ -938,6 +938,52 @@ __global__ void reinhard_kernel(const float *__restrict__ rgb, int64_t n_pixels,
 }
 
 // ---------------------------------------------------------------------------
+// Self-check of rtd::sqrt_exact / rtd::rsqrt_exact against the IEEE operations they stand for (sqrt(x), 1.0 / sqrt(x) as
+// the compiler expands them), bit for bit, over n arguments of one class:
+//   0  random significand, exponent uniform in 2^-60 .. 2^60 (the tracer's range)
+//   1  random bits over the whole double range: zero, denormals, infinities, NaN and negatives among them
+//   2  significands of mostly ones or mostly zeros around every exponent
+//   3  exact squares and their neighbours
+//   4  arguments whose square root has a significand of mostly ones (what the fast path hands to the generic form)
+__device__ inline double math_check_arg(int cls, uint64_t i, uint32_t seed)
+{
+    const rtd::U4 w = rtd::philox4x32_10((uint32_t)i, (uint32_t)(i >> 32), (uint32_t)cls, 0u, seed, 0x5eedu);
+    const uint64_t r = ((uint64_t)w.x << 32) | w.y, r2 = ((uint64_t)w.z << 32) | w.w;
+    const uint64_t frac = r & 0x000FFFFFFFFFFFFFull;
+    if (cls == 0) return __longlong_as_double((long long)(((uint64_t)(1023 - 60 + (r2 % 121)) << 52) | frac));
+    if (cls == 1) return __longlong_as_double((long long)r);
+    if (cls == 2) {
+        const int k = (int)(r2 % 53); // k low bits random, the rest all ones or all zeros
+        const uint64_t low = k ? (frac & ((1ull << k) - 1ull)) : 0ull;
+        const uint64_t high = ((r2 >> 8) & 1ull) ? (0x000FFFFFFFFFFFFFull & ~((1ull << k) - 1ull)) : 0ull;
+        return __longlong_as_double((long long)(((uint64_t)(1 + ((r2 >> 16) % 2046)) << 52) | high | low));
+    }
+    if (cls == 3) {
+        const double a = __longlong_as_double((long long)(((uint64_t)(1023 - 30 + (r2 % 61)) << 52) | (frac & 0x000FFFFFFC000000ull))); // 26 bits
+        return __longlong_as_double(__double_as_longlong(a * a) + ((int)((r2 >> 8) % 5) - 2)); // a * a is exact
+    }
+    const int k = (int)(r2 % 33);
+    const uint64_t sfrac = 0x000FFFFFFFFFFFFFull & ~(frac & ((1ull << k) - 1ull));
+    const double s = __longlong_as_double((long long)(((uint64_t)(1023 - 40 + ((r2 >> 8) % 81)) << 52) | sfrac));
+    return __longlong_as_double(__double_as_longlong(s * s) + ((int)((r2 >> 20) % 9) - 4));
+}
+
+__global__ __launch_bounds__(BLOCK) void math_check_kernel(int cls, uint64_t n, uint32_t seed, unsigned long long *mismatches)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * BLOCK;
+    unsigned long long mine = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) {
+        const double x = math_check_arg(cls, i, seed);
+        const double want = 1.0 / __builtin_sqrt(x), want_s = __builtin_sqrt(x);
+        const double got = rtd::rsqrt_exact(x), got_s = rtd::sqrt_exact(x);
+        const bool same = (__double_as_longlong(want) == __double_as_longlong(got) || (want != want && got != got)) &&
+                          (__double_as_longlong(want_s) == __double_as_longlong(got_s) || (want_s != want_s && got_s != got_s));
+        mine += same ? 0u : 1u;
+    }
+    if (mine) atomicAdd(mismatches + cls, mine);
+}
+
+// ---------------------------------------------------------------------------
 struct Render3dArgs {
     rt3d::SceneDev S;
     int32_t spp, bounce_limit, sample_offset, tiles_x;
