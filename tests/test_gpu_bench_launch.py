@@ -48,6 +48,11 @@ def test_the_merge_runs_over_rccl_with_one_rank(extra, merge_text, gpu_ctx):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "RT_BENCH_BACKEND")}
     env["RT_BENCH_FORCE_DIST"] = "1"
     env["RT_BENCH_WATCHDOG"] = "240"
+    import socket
+    with socket.socket() as sock:                      # a port of its own: the cases run back to back
+        sock.bind(("127.0.0.1", 0))
+        env["MASTER_PORT"] = str(sock.getsockname()[1])
+    env["MASTER_ADDR"] = "127.0.0.1"
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
                         "--configs", "none", "--cpu-spp", "0"] + extra, env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
