@@ -164,11 +164,13 @@ int32_t rt_ctx_synchronize(rt_ctx *ctx);
 int32_t rt_ctx_get_stats(rt_ctx *ctx, rt_stats *out);
 int32_t rt_ctx_reset_stats(rt_ctx *ctx);
 /* Self-check, no counterpart in the reference: the kernels compute sqrt(x) and 1 / sqrt(x) (glam's `normalize`,
- * the discriminants of Circle::hit and Sphere::hit) with their own instruction sequences, shorter than the compiler's
- * generic ones.  This runs both forms on the GPU over 2^log2_n arguments of each of five classes (the tracer's range,
- * random bit patterns with every special value, significands of mostly ones or zeros, exact squares and neighbours,
- * square roots next to a power of two) and returns how many results differ in any bit: all five must be 0. */
-int32_t rt_selftest_math(rt_ctx *ctx, int32_t log2_n, uint64_t seed, uint64_t *out_mismatches); /* [5] */
+ * the discriminants of Circle::hit and Sphere::hit) and x / 100 (the sky colour of the 3d tracer) with their own
+ * instruction sequences, shorter than the compiler's generic ones.  This runs both forms on the GPU - the square roots
+ * over 2^log2_n arguments of each of five classes (the tracer's range, random bit patterns with every special value,
+ * significands of mostly ones or zeros, exact squares and neighbours, square roots next to a power of two), the
+ * division, as class 5, over every float it is used on (all 2^32 patterns but the quotients that would be denormal,
+ * -0 and the infinities) - and returns how many results differ in any bit: all six must be 0. */
+int32_t rt_selftest_math(rt_ctx *ctx, int32_t log2_n, uint64_t seed, uint64_t *out_mismatches); /* [6] */
 
 /* ---- 2d: scene ----------------------------------------------------------- */
 /* Replaces borrowing `&World` (librt2d_reverse.rs:82,114): the arrays are copied. */

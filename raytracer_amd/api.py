@@ -220,7 +220,7 @@ class Context:
 
     def selftest_math(self, log2_n=24, seed=0x1234):
         """Mismatches per argument class between the kernels' own sqrt / reciprocal-sqrt sequences and the IEEE ones."""
-        out = (C.c_uint64 * 5)()
+        out = (C.c_uint64 * 6)()
         check(_ffi.lib().rt_selftest_math(self._ctx, int(log2_n), int(seed), out))
         return [int(v) for v in out]
 

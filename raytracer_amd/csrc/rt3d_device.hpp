@@ -542,12 +542,14 @@ RT_DEV bool shade(SceneK S, Path &p, const Hit &h, int bounce_limit, uint32_t k0
         float r = (1.0f - a) * 1.0f + a * 0.0f;
         float g = (1.0f - a) * 1.0f + a * 0.7f;
         float b = (1.0f - a) * 1.0f + a * 1.0f;
-        const double sl = rlen3(0.3, 1.0, 0.0);
+        // DVec3::new(0.3, 1., 0.).normalize() (rt.rs:283): constants, folded by the compiler with IEEE operations
+        const double sl = 1.0 / __builtin_sqrt((0.3 * 0.3 + 1.0 * 1.0) + 0.0 * 0.0);
         const double sx = 0.3 * sl, sy = 1.0 * sl, sz = 0.0 * sl;
         if ((p.dx * sx + p.dy * sy) + p.dz * sz > 0.99) { r = 240.0f; g = 255.0f; b = 170.0f; }
-        rgb[0] = p.thr * (r / 100.0f);
-        rgb[1] = p.thr * (g / 100.0f);
-        rgb[2] = p.thr * (b / 100.0f);
+        // r, g, b are +0 or in [2^-24, 255]: the range div_by_100 is exact on
+        rgb[0] = p.thr * div_by_100(r);
+        rgb[1] = p.thr * div_by_100(g);
+        rgb[2] = p.thr * div_by_100(b);
         return true;
     }
     const int s = h.slot;

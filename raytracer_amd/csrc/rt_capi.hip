@@ -1891,16 +1891,16 @@ int32_t rt_selftest_math(rt_ctx *ctx, int32_t log2_n, uint64_t seed, uint64_t *o
     void *ws = nullptr;
     if (int32_t rc = ctx_workspace(ctx, 256, &ws)) return rc;
     unsigned long long *d_bad = (unsigned long long *)ws;
-    HIP_TRY(hipMemsetAsync(d_bad, 0, 5 * sizeof(unsigned long long), ctx->stream));
-    for (int cls = 0; cls < 5; ++cls) {
+    HIP_TRY(hipMemsetAsync(d_bad, 0, 6 * sizeof(unsigned long long), ctx->stream));
+    for (int cls = 0; cls < 6; ++cls) {
         hipLaunchKernelGGL(rtk::math_check_kernel, dim3(256 * 32), dim3(rtk::BLOCK), 0, ctx->stream, cls, (uint64_t)1 << log2_n,
                            (uint32_t)seed + (uint32_t)cls, d_bad);
         HIP_TRY(hipGetLastError());
     }
-    unsigned long long h[5];
+    unsigned long long h[6];
     HIP_TRY(hipMemcpyAsync(h, d_bad, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    for (int i = 0; i < 5; ++i) out_mismatches[i] = h[i];
+    for (int i = 0; i < 6; ++i) out_mismatches[i] = h[i];
     return RT_OK;
 }
 

@@ -178,6 +178,20 @@ RT_DEV double sqrt_exact(double x)
     return s;
 }
 
+// fl(x / 100.0f), the division in `get_background_color(..) / 100.` (3d/src/rt.rs:234), in three instructions where the
+// generic f32 division takes ten: q0 = x * fl(1/100), the residual x - 100 q0 (exact in a fused step), q0 + residual *
+// fl(1/100).  Same bits for EVERY float whose exponent field is 3 .. 254 (2^-124 <= |x| < inf) and for +0: checked by
+// exhaustion over all 2^32 bit patterns on the GPU (rt_selftest_math, class 5; the only patterns that differ are
+// -0, the denormals and the two binades above them - whose quotients are denormal - and the infinities).  The caller's
+// arguments are sky colours in {+0} and [2^-24, 1].
+RT_DEV float div_by_100(float x)
+{
+    const float r = 0.01f; // fl(1 / 100) = 0x3C23D70A
+    const float q0 = x * r;
+    const float rem = __builtin_fmaf(-q0, 100.0f, x);
+    return __builtin_fmaf(rem, r, q0);
+}
+
 // 1/len with len = sqrt(x.x + y.y): glam's normalize multiplies by the reciprocal.
 RT_DEV double rlen2(double x, double y) { return rsqrt_exact(x * x + y * y); }
 RT_DEV double rlen3(double x, double y, double z) { return rsqrt_exact((x * x + y * y) + z * z); }

@@ -945,6 +945,8 @@ __global__ void reinhard_kernel(const float *__restrict__ rgb, int64_t n_pixels,
 //   2  significands of mostly ones or mostly zeros around every exponent
 //   3  exact squares and their neighbours
 //   4  arguments whose square root has a significand of mostly ones (what the fast path hands to the generic form)
+// and, class 5, of rtd::div_by_100 against x / 100.0f over ALL floats with an exponent field of 3 .. 254, and +0
+// (n is ignored: the class is exhaustive).
 __device__ inline double math_check_arg(int cls, uint64_t i, uint32_t seed)
 {
     const rtd::U4 w = rtd::philox4x32_10((uint32_t)i, (uint32_t)(i >> 32), (uint32_t)cls, 0u, seed, 0x5eedu);
@@ -972,6 +974,16 @@ __global__ __launch_bounds__(BLOCK) void math_check_kernel(int cls, uint64_t n, 
 {
     const uint64_t stride = (uint64_t)gridDim.x * BLOCK;
     unsigned long long mine = 0;
+    if (cls == 5) {
+        for (uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; i < (1ull << 32); i += stride) {
+            const uint32_t ex = ((uint32_t)i >> 23) & 255u;
+            if (!((ex >= 3u && ex <= 254u) || i == 0)) continue;
+            const float x = __uint_as_float((uint32_t)i);
+            mine += (__float_as_uint(x / 100.0f) == __float_as_uint(rtd::div_by_100(x))) ? 0u : 1u;
+        }
+        if (mine) atomicAdd(mismatches + cls, mine);
+        return;
+    }
     for (uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) {
         const double x = math_check_arg(cls, i, seed);
         const double want = 1.0 / __builtin_sqrt(x), want_s = __builtin_sqrt(x);
