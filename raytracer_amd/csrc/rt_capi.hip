@@ -692,6 +692,7 @@ int32_t launch_render2d(rt_ctx *ctx, const rt2d_scene *scene, const rt2d_render_
         const unsigned __int128 m = (num + (uint32_t)p->lambda_samples - 1) / (uint32_t)p->lambda_samples;
         A.ls_magic = (uint32_t)(m - ((unsigned __int128)1 << 32));
         A.ls_shift = sh;
+        A.inv_lambda_pow2 = ((p->lambda_samples & (p->lambda_samples - 1)) == 0) ? 1.0f / (float)p->lambda_samples : 0.0f;
     }
     {
         // work units of about 1024 items (a multiple of 64 pairs): small against a wave's share of the launch,

@@ -32,6 +32,9 @@ struct Render2dArgs {
     // ls_magic = ceil(2^(32 + ls_shift) / lambda_samples) - 2^32 (exact: the error term x e / 2^(32 + shift) stays below 1 / lambda_samples)
     uint32_t ls_magic;
     int32_t ls_shift;
+    // 1 / lambda_samples when that is a power of two (then x * inv == x / lambda_samples for every float x: both are
+    // the exactly scaled value, rounded once), else 0: the kernel divides
+    float inv_lambda_pow2;
     // a tile's (pixel, sample) pairs - 48 x spp of them, pixel fastest - are handed out in runs of `chunk` pairs;
     // unit u = run u / n_tiles of tile u % n_tiles; every pair stands for lambda_samples items
     int32_t chunk, n_units;
@@ -270,7 +273,8 @@ __global__ __launch_bounds__(BLOCK, (SMALL || NOSEG) ? 7 : 6) void render2d_kern
                 if (value != 0.0f) {
                     // per-sample term of `spectrum_spp / lambda_samples * 95` (librt2d_reverse.rs:104-105)
                     const float v = p.thr * value;
-                    const float c = v / (float)n_lambda * (float)NBINS;
+                    const float inv = Ak->inv_lambda_pow2; // wave-uniform: the division is ten instructions, every step
+                    const float c = (inv != 0.0f ? v * inv : v / (float)n_lambda) * (float)NBINS;
                     unsafeAtomicAdd(Ak->out + (int64_t)orow * NBINS + p.li, c);
                 }
                 act = false;
