@@ -196,7 +196,7 @@ def compare3d(got, want):
 
 
 @pytest.mark.parametrize("use_bvh", [False, True])
-@pytest.mark.parametrize("n,giant", [(1, False), (2, True), (3, False), (64, True), (257, False), (1000, True)])
+@pytest.mark.parametrize("n,giant", [(1, False), (2, True), (3, False), (4, False), (5, False), (6, True), (9, False), (64, True), (257, False), (1000, True)])
 def test_random_spheres_fed_batch(n, giant, use_bvh, gpu_ctx, oracle):
     rng = np.random.default_rng(10 * n + giant)
     s = random_scene3d(rng, n, giant, use_bvh)
