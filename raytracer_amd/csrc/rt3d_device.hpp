@@ -436,6 +436,9 @@ RT_DEV void walk_tree(SceneK S, double ox, double oy, double oz, double dx, doub
         return NONE;
     };
     RT_STAMP(prof, 1);
+#ifdef RT_PROF
+    const uint32_t visits_before = work.node_visits;
+#endif
     while (__any(node != NONE)) {
         while (__any(node >= 0)) {
 #ifdef RT_PROF
@@ -484,6 +487,18 @@ RT_DEV void walk_tree(SceneK S, double ox, double oy, double oz, double dx, doub
         }
         RT_STAMP(prof, 3);
     }
+#ifdef RT_PROF
+    if (active && prof.octants) { // does the direction's octant say how long a ray walks?
+        const unsigned long long nv = work.node_visits - visits_before;
+        unsigned long long *o = prof.octants + 4 * ((dx < 0.0 ? 1 : 0) | (dy < 0.0 ? 2 : 0) | (dz < 0.0 ? 4 : 0));
+        atomicAdd(o, 1ull);
+        if (nv > 1) {
+            atomicAdd(o + 1, 1ull);
+            atomicAdd(o + 2, nv);
+            atomicAdd(o + 3, nv * nv);
+        }
+    }
+#endif
 }
 
 // BVH = false: the reference's linear scan over every sphere (with the f32 filter ahead of the exact tests).

@@ -1815,6 +1815,15 @@ int32_t rt3d_accumulate(rt_ctx *ctx, const rt3d_scene *scene, const rt3d_render_
                         "exact-test rounds %.2f | cycles/step %.0f: refill %.3f setup+always %.3f walk %.3f leaves %.3f shade %.3f\n",
                 h[5], (double)h[6] / st, (double)h[7] / st, (double)h[8] / st, (double)h[10] / st, (double)h[9] / st, tot / st,
                 h[0] / tot, h[1] / tot, h[2] / tot, h[3] / tot, h[4] / tot);
+        unsigned long long all = 0;
+        for (int o = 0; o < 8; ++o) all += h[20 + 4 * o];
+        for (int o = 0; o < 8 && all; ++o) {
+            const unsigned long long *q = h + 20 + 4 * o;
+            const double n = (double)q[1], mean = n ? q[2] / n : 0.0, var = n ? q[3] / n - mean * mean : 0.0;
+            fprintf(stderr, "[rt_prof3d] octant %c%c%c: %.1f %% of the rays, %.1f %% of them go beyond the root: %.2f +- %.2f node visits\n",
+                    (o & 1) ? '-' : '+', (o & 2) ? '-' : '+', (o & 4) ? '-' : '+', 100.0 * q[0] / all, q[0] ? 100.0 * n / q[0] : 0.0, mean,
+                    var > 0.0 ? sqrt(var) : 0.0);
+        }
     }
 #endif
     ctx->samples += (uint64_t)scene->dev.width * (uint64_t)scene->dev.height * (uint64_t)p->spp;

@@ -202,6 +202,7 @@ RT_DEV double rlen3(double x, double y, double z) { return rsqrt_exact((x * x + 
 struct Prof {
     unsigned long long t[20];
     unsigned long long last;
+    unsigned long long *octants; // 3d: [8][4] rays, rays that go beyond the root, their node visits and the squares of those
 };
 #define RT_STAMP(prof, i)                                                              \
     do {                                                                               \

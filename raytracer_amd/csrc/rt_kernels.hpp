@@ -1065,6 +1065,7 @@ __global__ __launch_bounds__(BLOCK, 5) void render3d_kernel(const Render3dArgs A
     rtd::Prof prof{};
 #ifdef RT_PROF
     prof.last = __builtin_amdgcn_s_memtime();
+    prof.octants = Ak->prof_out ? Ak->prof_out + 20 : nullptr;
 #endif
     // adds the wave's accumulator to the image and clears it
     auto flush = [&](int ftx, int fty) {
