@@ -16,7 +16,9 @@ tag, dest = sys.argv[1], sys.argv[2]
 kernel = sys.argv[3] if len(sys.argv) > 3 else "render2d_kernel"
 src = os.path.join("gpurun_out", f"prof_{tag}")
 os.makedirs(dest, exist_ok=True)
-stats = glob.glob(os.path.join(src, "trace", "**", "*_kernel_stats.csv"), recursive=True)[0]
+# gpurun merges a call's files into what earlier calls left under the same tag: take the newest of each pass
+newest = lambda files: max(files, key=os.path.getmtime)
+stats = newest(glob.glob(os.path.join(src, "trace", "**", "*_kernel_stats.csv"), recursive=True))
 shutil.copy(stats, os.path.join(dest, f"kernel_stats_{tag}.csv"))
 out = {}
 for name in ("pmc_sq1", "pmc_sq2", "pmc_fetch", "pmc_write", "pmc_flop1", "pmc_flop2"):
@@ -24,7 +26,7 @@ for name in ("pmc_sq1", "pmc_sq2", "pmc_fetch", "pmc_write", "pmc_flop1", "pmc_f
     if not files:
         continue
     agg, disp = collections.defaultdict(float), set()
-    for r in csv.DictReader(open(files[0])):
+    for r in csv.DictReader(open(newest(files))):
         if kernel in r["Kernel_Name"]:
             agg[r["Counter_Name"]] += float(r["Counter_Value"])
             disp.add(r["Dispatch_Id"])
