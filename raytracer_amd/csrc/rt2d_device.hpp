@@ -36,13 +36,13 @@ typedef const SegX __attribute__((address_space(4))) *K_SegX;
 // Two circles as the f32 filter reads them (see filter_word): centre - frame centre and the padded r^2 of both.
 struct CirclePair { f32x2 vx, vy, e; };
 typedef const CirclePair __attribute__((address_space(4))) *K_CirclePair;
-// Two segments as the f32 filter reads them, each field holding the value of both: s = b - a, cs = A x s,
-// A = a - frame centre.  One record per pair keeps the loop's scalar side to one address and two loads; five
-// separate arrays cost five loads and ten address instructions per pair, more than the pair's vector work.
-struct SegPair { f32x2 sx, sy, cs, ax, ay; };
+// Two segments as the f32 filter reads them, each field holding the value of both: the end points relative to the
+// frame centre, A = a - m and B = b - m.  One 32-byte record per pair keeps the loop's scalar side to one address and
+// one load; separate arrays cost a load and two address instructions each, more than the pair's vector work.
+struct SegPair { f32x2 ax, ay, bx, by; };
 typedef const SegPair __attribute__((address_space(4))) *K_SegPair;
-// Margins of the segment filter for one launch (see filter_word).
-struct SegBounds { float eq, ep; };
+// Margin of the segment filter for one launch (see filter_word).
+struct SegBounds { float eq, pad_; };
 
 // Scene in HBM.  Slot order: circles by ascending pid, then segments by ascending pid.
 // A circle as the exact test and the shading read it: one 32-byte record, two 16-byte loads from one address.
@@ -163,34 +163,30 @@ RT_DEV bool segment_t(double ox, double oy, double rx, double ry, double ax, dou
 //      three more packed operations per pair on EVERY circle, which is more than the
 //      extra candidates cost in phase 2.
 //      Lanes whose origin or direction lies outside the frame mark every slot.
-//    segment, f32 with fused ops, same frame (U = o - m, A = a - m, s = b - a, |s_i| <= S):
-//      the reference accepts iff t = tn / den >= 0 and 0 <= u = un / den <= 1 with
-//        den = d x s,   tn = (A - U) x s = (A x s) - U x s,   un = (A - U) x d = A x d - (U x d),
-//      (A x s) per segment and (U x d) per ray.  0 <= u <= 1 is "un lies between 0 and den", i.e.
-//      Q = un (un - den) <= 0 whatever the sign of den, and t >= 0 is P = tn den >= 0.  A segment
-//      is dropped when Q > 0 or P < 0 SURELY.  Absolute errors of the f32 values (eps = 2^-24,
-//      |d_i| <= 1.0005; rounding of the inputs, of the per-ray / per-segment terms and of each
-//      fused step): |den| 7.1 eps S, |tn| 13.1 eps B S, |un| 10.7 eps B, |un - den| 15 eps B + 10.1 eps S.
-//      With the bounds Ed = 12 eps S, Et = 16 eps B S, Eu = 12 eps B, Ew = 20 eps (B + S) (which also
-//      absorb the rounding of the products) a product x y of values known to within Ex, Ey lies
-//      within |x| Ey + |y| Ex + Ex Ey of the true one.  The magnitudes are bounded per launch,
-//      |un| <= 2.83 B, |un - den| <= 2.83 B + 1.42 S, |tn| <= 4.02 B S, |den| <= 1.42 S (|A - U| <= 2 sqrt2 B,
-//      |s| <= sqrt2 S), so Q and P are compared against two constants of the launch,
-//        eq = 2.83 B Ew + (2.83 B + 1.42 S) Eu + Eu Ew,   ep = 4.02 B S Ed + 1.42 S Et + Et Ed   (+1 %),
-//      instead of per-segment margins: no absolute values, and the whole test is packed arithmetic, two
-//      segments per instruction.  The constant margins pass a sliver more (a band of about eq / den^2 of
-//      the segment's length past each end, ep / den^2 behind the origin); the exact test drops those.  The
-//      reference's own f64 rounding (and its -0.0 from an underflowing quotient) is many orders of
-//      magnitude inside these margins.  9 packed operations per pair plus an OR and a v_alignbit per segment.
+//    segment, f32 with fused ops, same frame (U = o - m, A = a - m, B = b - m, all within the frame's half width in
+//      every component): the reference accepts iff t >= 0 and 0 <= u <= 1, u the position of the crossing along the
+//      segment.  0 <= u <= 1 says that the end points lie on opposite sides of the ray's line (or on it):
+//        ca = (A - U) x d = A x d - (U x d),   cb = (B - U) x d = B x d - (U x d),   Q = ca cb <= 0
+//      (ca is the reference's `un`, cb = un - den), with (U x d) per ray: two fused steps per end point and one for
+//      g = eq - ca cb, whose sign bit is the drop bit.  Absolute error of a computed c (eps = 2^-24, |d_i| <= 1.0005):
+//      the rounded end point and direction 4.01 eps B, the rounded per-ray term 1.42 eps B, the two fused steps
+//      (intermediate <= 2.42 B, result <= 2.84 B) 5.26 eps B - together 10.7 eps B; with Eu = 12 eps B and |c| <=
+//      2.83 B (|A - U| <= 2 sqrt2 B) the computed product exceeds the true one by at most eq = 2 x 2.83 B Eu + Eu^2
+//      (+1 %), a constant of the launch: no absolute values, no per-segment margins, and g >= 0 whenever the true
+//      Q <= 0.  The reference's own f64 rounding of un and den (and its -0.0 from an underflowing quotient) is many
+//      orders of magnitude inside that margin.  The margin passes a sliver more (a band of about eq / den^2 of the
+//      segment's length past each end); segments BEHIND the ray pass as well, as circles behind it do - the exact test
+//      drops both.  (A second product for t >= 0, tn den >= -ep with tn = (A - U) x s, dropped them here at the price of
+//      13 instead of 7 instructions per pair on every segment: 21.9 against 20.0 ms per launch on `sample_world`.)
+//      5 packed operations per pair and a v_alignbit per segment.
 //  phase 2 (marked slots only, shared out over the wave's lanes, see nearest_hit):
 //    the exact test in the reference's operation order, then (total_cmp key, pid)
 //    lexicographic minimum = "first minimum in scan order" (librt2d_reverse.rs:139).
 // Inactive lanes run phase 1 with the wave and mark nothing.
-// Per-ray operands of the circle filter, each duplicated into both halves of a packed register.
+// Per-ray operands of both filters, each duplicated into both halves of a packed register.
 struct FilterRay {
     f32x2 ndx, dy; // -d.x, d.y
-    f32x2 kc;      // d x u
-    f32x2 nux, uy, nku; // segments: -u.x, u.y and -(u x d)
+    f32x2 kc;      // d x u = -(u x d): the per-ray term of the circles' X and of the segments' ca, cb alike
 };
 
 RT_DEV FilterRay filter_ray(SceneK S, double ox, double oy, double dx, double dy, bool &in_range)
@@ -204,10 +200,6 @@ RT_DEV FilterRay filter_ray(SceneK S, double ox, double oy, double dx, double dy
     f.ndx = f32x2{ -dxf, -dxf };
     f.dy = f32x2{ dyf, dyf };
     f.kc = f32x2{ kc, kc };
-    const float uxf = (float)ux, uyf = (float)uy, nku = -(float)(ux * dy - uy * dx);
-    f.nux = f32x2{ -uxf, -uxf };
-    f.uy = f32x2{ uyf, uyf };
-    f.nku = f32x2{ nku, nku };
     return f;
 }
 
@@ -230,18 +222,15 @@ RT_DEV uint32_t filter_circle_word(K_CirclePair cp, const FilterRay &f, uint32_t
 RT_DEV uint32_t filter_segment_word(K_SegPair gp, const SegBounds &E, const FilterRay &f, uint32_t force)
 {
     uint32_t acc = 0;
-    const f32x2 eq = { E.eq, E.eq }, ep = { E.ep, E.ep };
+    const f32x2 eq = { E.eq, E.eq };
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
-        const f32x2 sx = gp[k].sx, sy = gp[k].sy, cs = gp[k].cs, ax = gp[k].ax, ay = gp[k].ay;
-        const f32x2 den = __builtin_elementwise_fma(-f.ndx, sy, -(f.dy * sx));
-        const f32x2 tn = __builtin_elementwise_fma(f.uy, sx, __builtin_elementwise_fma(f.nux, sy, cs));
-        const f32x2 un = __builtin_elementwise_fma(ax, f.dy, __builtin_elementwise_fma(ay, f.ndx, f.nku));
-        const f32x2 w = un - den;
-        const f32x2 rq = __builtin_elementwise_fma(-un, w, eq);
-        const f32x2 rp = __builtin_elementwise_fma(tn, den, ep);
-        acc = __builtin_amdgcn_alignbit(acc, __float_as_uint(rq.x) | __float_as_uint(rp.x), 31);
-        acc = __builtin_amdgcn_alignbit(acc, __float_as_uint(rq.y) | __float_as_uint(rp.y), 31);
+        const f32x2 ax = gp[k].ax, ay = gp[k].ay, bx = gp[k].bx, by = gp[k].by;
+        const f32x2 ca = __builtin_elementwise_fma(ax, f.dy, __builtin_elementwise_fma(ay, f.ndx, f.kc));
+        const f32x2 cb = __builtin_elementwise_fma(bx, f.dy, __builtin_elementwise_fma(by, f.ndx, f.kc));
+        const f32x2 g = __builtin_elementwise_fma(-ca, cb, eq);
+        acc = __builtin_amdgcn_alignbit(acc, __float_as_uint(g.x), 31);
+        acc = __builtin_amdgcn_alignbit(acc, __float_as_uint(g.y), 31);
     }
     return ~acc | force;
 }
@@ -264,32 +253,27 @@ RT_DEV uint32_t filter_word(int n_circ, K_CirclePair c32, K_SegPair segp, const 
         acc = __builtin_amdgcn_alignbit(acc, __float_as_uint(g.y), 31);
     }
     // two segments per packed instruction as well (the segment arrays are padded to an even count; the first
-    // segment slot, n_circ, is even).  Drop bits again: sign(rq) | sign(rp).
+    // segment slot, n_circ, is even).  Drop bits again: the sign of g.
     const int s_lo = lo > n_circ ? lo : n_circ;
-    const f32x2 eq = { E.eq, E.eq }, ep = { E.ep, E.ep };
-    auto pair = [&](K_SegPair gp, f32x2 &rq, f32x2 &rp) {
-        const f32x2 sx = gp->sx, sy = gp->sy, cs = gp->cs, ax = gp->ax, ay = gp->ay;
-        const f32x2 den = __builtin_elementwise_fma(-f.ndx, sy, -(f.dy * sx));                              // d x s
-        const f32x2 tn = __builtin_elementwise_fma(f.uy, sx, __builtin_elementwise_fma(f.nux, sy, cs));     // (A - U) x s
-        const f32x2 un = __builtin_elementwise_fma(ax, f.dy, __builtin_elementwise_fma(ay, f.ndx, f.nku));  // (A - U) x d
-        const f32x2 w = un - den;
-        rq = __builtin_elementwise_fma(-un, w, eq);  // < 0: u surely outside [0, 1]
-        rp = __builtin_elementwise_fma(tn, den, ep); // < 0: t surely negative
+    const f32x2 eq = { E.eq, E.eq };
+    auto pair = [&](K_SegPair gp) {
+        const f32x2 ax = gp->ax, ay = gp->ay, bx = gp->bx, by = gp->by;
+        const f32x2 ca = __builtin_elementwise_fma(ax, f.dy, __builtin_elementwise_fma(ay, f.ndx, f.kc)); // (A - U) x d
+        const f32x2 cb = __builtin_elementwise_fma(bx, f.dy, __builtin_elementwise_fma(by, f.ndx, f.kc)); // (B - U) x d
+        return __builtin_elementwise_fma(-ca, cb, eq); // < 0: the end points surely lie on one side of the ray's line
     };
     if (WITH_SEGMENTS) {
         int s = s_lo;
         K_SegPair gp = segp + ((s_lo - n_circ) >> 1);
 #pragma unroll 2
         for (; s + 2 <= hi; s += 2, ++gp) {
-            f32x2 rq, rp;
-            pair(gp, rq, rp);
-            acc = __builtin_amdgcn_alignbit(acc, __float_as_uint(rq.x) | __float_as_uint(rp.x), 31);
-            acc = __builtin_amdgcn_alignbit(acc, __float_as_uint(rq.y) | __float_as_uint(rp.y), 31);
+            const f32x2 g = pair(gp);
+            acc = __builtin_amdgcn_alignbit(acc, __float_as_uint(g.x), 31);
+            acc = __builtin_amdgcn_alignbit(acc, __float_as_uint(g.y), 31);
         }
         if (s < hi) { // an odd segment count ends on half a pair: the other half is the padding element
-            f32x2 rq, rp;
-            pair(gp, rq, rp);
-            acc = __builtin_amdgcn_alignbit(acc, __float_as_uint(rq.x) | __float_as_uint(rp.x), 31);
+            const f32x2 g = pair(gp);
+            acc = __builtin_amdgcn_alignbit(acc, __float_as_uint(g.x), 31);
         }
     }
     // keep = not drop.  The ones this puts above the collected bits are shifted out below: exactly hi - lo bits
@@ -334,7 +318,7 @@ RT_DEV Hit nearest_hit(SceneK S, double ox, double oy, double dx, double dy, boo
     const CircleX *cex = S->cex;
     const SegX *sex = S->sex;
     const K_SegPair segp = (K_SegPair)S->segp;
-    const SegBounds E = { S->seg_bounds.eq, S->seg_bounds.ep };
+    const SegBounds E = { S->seg_bounds.eq, 0.0f };
     const int lane = lane_id();
     // outside the frame the f32 filter is proven for, every slot becomes a candidate (exact tests decide)
     bool in_range;

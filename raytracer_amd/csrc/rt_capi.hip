@@ -119,7 +119,6 @@ struct rt2d_scene {
     int n_prims = 0;
     double lo[2] = { 0.0, 0.0 }, hi[2] = { 0.0, 0.0 }; // bounding box of every primitive (circles with their radius)
     int n_circles = 0;                                   // without the slot that pads an odd count
-    double seg_extent = 0.0;                             // largest |b - a| component of a segment
     mutable double padded_for = -1.0;                    // filt_M the device's c32e array currently holds
     mutable int users = 0;                               // progressive renderers bound to this scene
     // forward tracer: emissive objects in object order; emitter_bad = first emissive object that is not a circle (-1: none)
@@ -501,15 +500,14 @@ int32_t rt2d_scene_create(rt_ctx *ctx, const rt2d_scene_desc *d, rt2d_scene **ou
                 // s = b - a, rt_common.rs:244
                 H(sex)[k] = rt2d::SegX{ d->seg_ax[i], d->seg_ay[i], d->seg_bx[i] - d->seg_ax[i], d->seg_by[i] - d->seg_ay[i],
                                         d->seg_nx[i], d->seg_ny[i], d->seg_pid[i], d->seg_obj[i], 0.0 };
-                const double Ax = d->seg_ax[i] - fmx, Ay = d->seg_ay[i] - fmy;
-                const double sx = d->seg_bx[i] - d->seg_ax[i], sy = d->seg_by[i] - d->seg_ay[i];
                 rt2d::SegPair &q = H(segp)[k >> 1];
                 const int h = k & 1;
-                q.sx[h] = (float)sx; q.sy[h] = (float)sy; q.cs[h] = (float)(Ax * sy - Ay * sx); q.ax[h] = (float)Ax; q.ay[h] = (float)Ay;
+                q.ax[h] = (float)(d->seg_ax[i] - fmx); q.ay[h] = (float)(d->seg_ay[i] - fmy);
+                q.bx[h] = (float)(d->seg_bx[i] - fmx); q.by[h] = (float)(d->seg_by[i] - fmy);
             }
             if (nsp2 > ns) { // padding half of an odd count: read with the last segment, its result is discarded
                 rt2d::SegPair &q = H(segp)[ns >> 1];
-                q.sx[1] = q.sy[1] = q.cs[1] = q.ax[1] = q.ay[1] = 0.0f;
+                q.ax[1] = q.ay[1] = q.bx[1] = q.by[1] = 0.0f;
             }
             for (int i = 0; i < no; ++i) {
                 const rt2d_material &m = d->materials[i];
@@ -550,9 +548,6 @@ int32_t rt2d_scene_create(rt_ctx *ctx, const rt2d_scene_desc *d, rt2d_scene **ou
     sc->ctx = ctx;
     sc->n_prims = P;
     sc->n_circles = nc;
-    sc->seg_extent = 0.0;
-    for (int i = 0; i < ns; ++i)
-        sc->seg_extent = std::max(sc->seg_extent, std::max(std::fabs(d->seg_bx[i] - d->seg_ax[i]), std::fabs(d->seg_by[i] - d->seg_ay[i])));
     sc->lo[0] = blo[0]; sc->lo[1] = blo[1]; sc->hi[0] = bhi[0]; sc->hi[1] = bhi[1];
     sc->emitters = emitters;
     sc->emitter_bad = emitter_bad;
@@ -626,13 +621,12 @@ int32_t filter_frame(rt_ctx *ctx, const rt2d_scene *scene, const double lo[2], c
     S.filt_B = B;
     S.filt_M = 64.0 * 0x1.0p-24 * B * B;
     {
-        // bounds of the segment filter (derivation in rt2d_device.hpp), rounded up
-        const double eps = 0x1.0p-24, Sx = std::max(scene->seg_extent, 0x1.0p-300);
+        // margin of the segment filter (derivation in rt2d_device.hpp), rounded up
+        const double eps = 0x1.0p-24;
         auto up = [](double v) { return std::nextafterf((float)v, INFINITY); };
-        const double ed = 12.0 * eps * Sx, et = 16.0 * eps * B * Sx, eu = 12.0 * eps * B, ew = 20.0 * eps * (B + Sx);
-        const double eq = 2.83 * B * ew + (2.83 * B + 1.42 * Sx) * eu + eu * ew;
-        const double ep = 4.02 * B * Sx * ed + 1.42 * Sx * et + et * ed;
-        S.seg_bounds = rt2d::SegBounds{ up(eq * 1.01), up(ep * 1.01) };
+        const double eu = 12.0 * eps * B;
+        const double eq = 2.0 * 2.83 * B * eu + eu * eu;
+        S.seg_bounds = rt2d::SegBounds{ up(eq * 1.01), 0.0f };
     }
     if (scene->padded_for != S.filt_M && scene->n_circles > 0) {
         // the padded radii live in the scene's blob: launches on one scene are ordered on the context's stream

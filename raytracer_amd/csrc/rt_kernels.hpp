@@ -100,7 +100,7 @@ struct PairSlab {
 // numbered run-major so that the waves working at the same time are on different tiles.  A finished sample is added
 // to its pixel's bin in HBM with a hardware f32 atomic (the tile's 18 KB stay in L2 while a unit lasts).
 template <bool SEGW, bool SMALL = false, bool NOSEG = false>
-__global__ __launch_bounds__(BLOCK, (SMALL || NOSEG) ? 7 : 6) void render2d_kernel(const Render2dArgs A)
+__global__ __launch_bounds__(BLOCK, 7) void render2d_kernel(const Render2dArgs A)
 {
     __shared__ rt2d::CoopLds coop[SMALL ? 1 : BLOCK / 64];
     __shared__ ItemPool pools[BLOCK / 64];
