@@ -287,8 +287,9 @@ struct CoopLds {
     int64_t key[64];      // running minimum total_cmp key of each lane's ray
     uint64_t pidslot[64]; // (pid << 32 | slot) of the lowest pid among the hits that have that key
     // queue of candidate words: mask (MSB = the word's first slot) and owner lane | word index within the 256-slot tile << 6
+    // (two arrays of one element size: an entry's two cells then share one address computation)
     uint32_t ring_bits[128];
-    uint16_t ring_info[128];
+    uint32_t ring_info[128];
 };
 
 // Phase 2 is shared by the wave.  A lane's own candidates are few (1.8 on average on the stress scene)
@@ -422,7 +423,7 @@ RT_DEV Hit nearest_hit(SceneK S, double ox, double oy, double dx, double dy, boo
             if (mw != 0u) {
                 const int at = (head + count + rank_in_mask(fresh)) & 127;
                 L.ring_bits[at] = mw;
-                L.ring_info[at] = (uint16_t)(lane | ((lo & 255) << 1)); // (lo & 255) / 32 << 6
+                L.ring_info[at] = (uint32_t)(lane | ((lo & 255) << 1)); // (lo & 255) / 32 << 6
             }
             count += __popcll(fresh);
         }
@@ -478,7 +479,7 @@ RT_DEV Hit nearest_hit(SceneK S, double ox, double oy, double dx, double dy, boo
                 if (bits != 0u) {
                     const int at = (head + count + rank_in_mask(again)) & 127;
                     L.ring_bits[at] = bits;
-                    L.ring_info[at] = (uint16_t)info;
+                    L.ring_info[at] = info;
                 }
                 count += __popcll(again);
             }

@@ -61,15 +61,20 @@ __global__ __launch_bounds__(BLOCK) void pad_radii_kernel(const rt2d::CircleX *_
     c32[k >> 1].e[k & 1] = f;
 }
 
-// Per-wave LDS of render2d_kernel, 15 dwords per lane.  Between steps it is the pool of rays that have taken their
+// Per-wave LDS of render2d_kernel, 14 dwords per lane.  Between steps it is the pool of rays that have taken their
 // first bounce and wait for a free lane (rows 0..12: origin and direction as four doubles, collected factors,
 // wavelength bin | lambda-sample << 8, output row, Philox counter words); during an intake step, while it is empty,
-// the lanes park their own paths in it (all 15 rows).
+// the lanes park their own paths in it (all 14 rows; the last holds depth_left (< 2^12) | lambda-sample << 12).
+// Together with the candidate queue that is 5 632 bytes per wave: seven workgroups fill 157.7 of a CU's 160 KB.
+// WIDE (the kernels without a candidate queue, which have the room): depth_left and the lambda-sample in rows of
+// their own, two instructions less per intake step.
+template <bool WIDE>
 struct ItemPool {
     double ox[64], oy[64], dx[64], dy[64];
     float thr[64];
     uint32_t meta[64], row[64], c0[64], c1[64];
-    uint32_t park_depth[64], park_c2[64];
+    uint32_t park[64];
+    uint32_t park_c2[WIDE ? 64 : 1];
 };
 
 // The (pixel, sample) pairs a wave is working through, in global memory (one slab per resident wave, written once
@@ -103,7 +108,7 @@ template <bool SEGW, bool SMALL = false, bool NOSEG = false>
 __global__ __launch_bounds__(BLOCK, 7) void render2d_kernel(const Render2dArgs A)
 {
     __shared__ rt2d::CoopLds coop[SMALL ? 1 : BLOCK / 64];
-    __shared__ ItemPool pools[BLOCK / 64];
+    __shared__ ItemPool<SMALL> pools[BLOCK / 64];
     // the arguments are read in place (kernel-argument segment), see rt2d::SceneK
     typedef const Render2dArgs __attribute__((address_space(4))) *ArgsK;
     ArgsK Ak = (ArgsK)__builtin_amdgcn_kernarg_segment_ptr();
@@ -124,7 +129,7 @@ __global__ __launch_bounds__(BLOCK, 7) void render2d_kernel(const Render2dArgs A
     int set_lambda = n_lambda; // wave-uniform: next lambda-sample of the pair set in the slab to take in (n_lambda: none left)
     // the wave's index as a scalar: the addresses of its pool and slab rows are then scalar base + lane offset
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    ItemPool &pool = pools[wave];
+    ItemPool<SMALL> &pool = pools[wave];
     PairSlab &slab = Ak->pairs[blockIdx.x * (BLOCK / 64) + wave];
     uint32_t orow = 0;     // row of `out` this lane's path adds to
     uint32_t set_bins = 0; // wavelength bins of four consecutive lambda-samples of this lane's pair of the set, one byte each
@@ -197,7 +202,11 @@ __global__ __launch_bounds__(BLOCK, 7) void render2d_kernel(const Render2dArgs A
             pool.ox[lane] = p.ox; pool.oy[lane] = p.oy; pool.dx[lane] = p.dx; pool.dy[lane] = p.dy;
             pool.thr[lane] = p.thr; pool.meta[lane] = (uint32_t)p.li; pool.row[lane] = orow;
             pool.c0[lane] = p.c0; pool.c1[lane] = p.c1;
-            pool.park_depth[lane] = (uint32_t)p.depth_left; pool.park_c2[lane] = p.c2;
+            if (SMALL) {
+                pool.park[lane] = (uint32_t)p.depth_left; pool.park_c2[lane] = p.c2;
+            } else {
+                pool.park[lane] = (uint32_t)p.depth_left | (p.c2 << 12);
+            }
             asm volatile("" ::: "memory");
             // which pair this lane stands for: the same for every lambda-sample of the set, so it is recomputed
             // rather than kept in the slab
@@ -291,7 +300,13 @@ __global__ __launch_bounds__(BLOCK, 7) void render2d_kernel(const Render2dArgs A
             p.ox = pool.ox[lane]; p.oy = pool.oy[lane]; p.dx = pool.dx[lane]; p.dy = pool.dy[lane];
             p.thr = pool.thr[lane]; p.li = (int)pool.meta[lane]; orow = pool.row[lane];
             p.c0 = pool.c0[lane]; p.c1 = pool.c1[lane];
-            p.depth_left = (int)pool.park_depth[lane]; p.c2 = pool.park_c2[lane];
+            if (SMALL) {
+                p.depth_left = (int)pool.park[lane]; p.c2 = pool.park_c2[lane];
+            } else {
+                const uint32_t pk = pool.park[lane];
+                p.depth_left = (int)(pk & 0xFFFu);
+                p.c2 = pk >> 12;
+            }
             const uint64_t cont = __ballot(act);
             __builtin_amdgcn_wave_barrier();
             if (act) {
