@@ -407,6 +407,15 @@ typedef struct {
     double first_t;
 } path_info;
 
+/* A normal no direction can have a positive product with: the zero vector (a caller's segment normal), or NaN
+ * (Circle::hit's `(p - center).normalize()`, rt_common.rs:103, when the hit point rounds onto the centre - a circle
+ * smaller than the spacing of f64 at its coordinates).  The reference's rejection loop below never returns for such a
+ * normal; here, and in the kernels, the path ends at that hit and contributes nothing. */
+static int no_direction(dv2 n)
+{
+    return !(fabs(n.x) + fabs(n.y) > 0.0);
+}
+
 /* Ray2d::rand_hemisphere, 2d/src/rt_common.rs:376-391 */
 static dv2 rand_hemisphere(const rng_stream *rs, uint32_t bounce, dv2 n)
 {
@@ -505,6 +514,7 @@ static float trace_ray2d(const prep2d *pp, dv2 o, dv2 d, int lambda_idx, double 
     switch (m->kind) {
     case RTO_DIFFUSE: {
         if (pp->diffuse_black[best_obj]) return 0.0f;
+        if (no_direction(best.n)) return 0.0f;
         dv2 p = { best.p.x + best.n.x * 10000.0 * EPS, best.p.y + best.n.y * 10000.0 * EPS };
         dv2 nd = rand_hemisphere(rs, (uint32_t)bounce, best.n);
         float light = trace_ray2d(pp, p, nd, lambda_idx, lambda, depth - 1, recursion_limit, rs, info);
@@ -855,6 +865,7 @@ static int forward_trace(const prep2d *pp, dv2 o, dv2 d, int lambda_idx, double 
     switch (m->kind) { /* Outside, :120-194 */
     case RTO_DIFFUSE: {
         if (pp->diffuse_black[best_obj]) return 0;
+        if (no_direction(best.n)) return 0;
         dv2 p = { best.p.x + best.n.x * 10000.0 * EPS, best.p.y + best.n.y * 10000.0 * EPS };
         dv2 nd = rand_hemisphere(rs, (uint32_t)bounce, best.n);
         float new_power = spec[lambda_idx] * power;

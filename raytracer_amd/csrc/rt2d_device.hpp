@@ -618,7 +618,12 @@ RT_DEV ShadeResult shade(SceneK S, Path &p, const Hit &h, float &value, double &
         }
         RT_STAMP(prof, 9);
     } else {
-        // Diffuse (:211-224): new origin p + n*1e4*eps, factor `absorption[lambda]`; direction drawn by the wave
+        // Diffuse (:211-224): new origin p + n*1e4*eps, factor `absorption[lambda]`; direction drawn by the wave.
+        // A normal that is the zero vector (a caller's segment normal) or NaN (a hit point that rounds onto a
+        // circle's centre: the circle is smaller than the spacing of f64 at its coordinates) has a positive product
+        // with no direction: the reference's rejection loop (rt_common.rs:376-391) never returns for it, and neither
+        // would the wave's.  Such a path ends here and contributes nothing.
+        if (!(__builtin_fabs(nx) + __builtin_fabs(ny) > 0.0)) return SHADE_DONE;
         p.ox = hx + nx * 10000.0 * EPS64;
         p.oy = hy + ny * 10000.0 * EPS64;
         p.thr = p.thr * sv;

@@ -174,6 +174,37 @@ def test_scene_far_from_the_coordinate_origin(gpu_ctx, oracle):
     scene.close()
 
 
+@pytest.mark.timeout(60)
+def test_a_hit_point_on_a_circles_centre_ends_the_path(gpu_ctx, oracle):
+    """Diffuse circles far smaller than the spacing of f64 at their coordinates (radius 1e-9 at 1e9): a ray through
+    the centre hits at the centre itself, the normal is NaN, and no direction of the reference's rejection loop
+    (rt_common.rs:376-391) would ever be accepted.  The kernels end such a path (as the checker does) instead of
+    looping; the rays that miss, and the bounces off an ordinary circle beside it, are unaffected."""
+    spectra = np.stack([np.full(95, 0.5, np.float32), np.full(95, 2.0, np.float32)])
+    mats = np.array([[2, 0, 1.5, 0.0, 0.0, 1.0, 0], [2, 0, 1.5, 0.0, 0.0, 1.0, 0], [0, 0, 1.0, 0.0, 0.0, 1.0, 1]], float)
+    z, zi = np.zeros(0), np.zeros(0, np.int32)
+    a = dict(materials=mats, spectra=spectra,
+             circle_cx=np.array([1e9, 1e9 + 40.0, 1e9 - 200.0]), circle_cy=np.array([1e9, 1e9 + 3.0, 1e9]),
+             circle_r=np.array([1e-9, 5.0, 100.0]), circle_obj=np.array([0, 1, 2], np.int32), circle_pid=np.array([0, 1, 2], np.int32),
+             seg_ax=z, seg_ay=z, seg_bx=z, seg_by=z, seg_nx=z, seg_ny=z, seg_obj=zi, seg_pid=zi)
+    world = rt.ArrayWorld2D(a)
+    scene = rt.Scene2D(gpu_ctx, world)
+    n = 4096
+    rng = np.random.default_rng(5)
+    # from points on a circle of radius 10 around the tiny circle, straight at its centre (half of them), or anywhere
+    phi = rng.random(n) * 2 * np.pi
+    ox, oy = 1e9 + 10.0 * np.cos(phi), 1e9 + 10.0 * np.sin(phi)
+    aim = rng.random(n) < 0.5
+    ang = np.where(aim, np.arctan2(1e9 - oy, 1e9 - ox), rng.random(n) * 2 * np.pi)
+    rays = (ox, oy, np.cos(ang), np.sin(ang), rng.integers(0, 95, n).astype(np.int32))
+    got, want = scene.trace_batch(*rays, depth=10, seed=2), oracle.trace_batch2d(world, *rays, depth=10, seed=2)
+    compare(got, want)
+    dead = (got[1] == 0) & (got[3] == 1)
+    assert dead.sum() > 10 and (got[0][dead] == 0.0).all()      # paths that ended on the tiny circle
+    assert (got[0] > 0).sum() > 100                              # and others that found the light
+    scene.close()
+
+
 def test_context_outlives_its_scenes():
     from raytracer_amd import _ffi
     ctx = rt.Context(0)

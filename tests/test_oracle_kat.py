@@ -216,6 +216,16 @@ def test_black_diffuse_short_circuits_and_white_diffuse_bounces(oracle):
     assert (rad == 0.5).any() and nb.max() <= 3
 
 
+@pytest.mark.timeout(60)
+def test_a_hit_point_on_a_circles_centre_ends_the_path(oracle):
+    """A circle smaller than the spacing of f64 at its coordinates: the hit point rounds onto the centre,
+    `(p - center).normalize()` (rt_common.rs:103) is NaN, and the reference's rejection loop for the diffuse direction
+    (rt_common.rs:376-391) would never accept.  Checker and kernels end the path there instead."""
+    w = scene(circles=[(1e9, 1e9, 1e-9, 0)], materials=[mat(DIFFUSE, 0)], spectra=[np.full(95, 0.5)])
+    assert one_ray(oracle, w, (1e9 - 10.0, 1e9), (1, 0)) == (0.0, 0, 10.0, 1)
+    assert one_ray(oracle, w, (1e9 - 10.0, 1e9 + 1.0), (1, 0)) == (0.0, -1, -1.0, 1)
+
+
 # ---- compute_pixel / to_xyz / Reinhard
 def test_compute_pixel_normalisation(oracle):
     # every sample starts inside the light of simple_world -> each lambda-sample returns e = 10;
