@@ -67,7 +67,7 @@ for w in range(n_worlds):
         bad += 1
         print(f"world {w} ({n_circ} circles, {n_seg} segments, scale {scale}, offset {off}): MISMATCH "
               f"ids {int((got[1] != want[1]).sum())} bounces {int((got[3] != want[3]).sum())} t {int((got[2] != want[2]).sum())}", flush=True)
-    if w % 10 == 9:
+    if w % 100 == 99:
         print(f"{w + 1} worlds, {bad} with a mismatch, {time.time() - t0:.0f} s", flush=True)
 ctx.close()
 print(f"done: {n_worlds} worlds x {n_rays} rays ({hits / (n_worlds * n_rays):.2f} of them hit something first), {bad} with a mismatch")
