@@ -53,4 +53,4 @@ def test_checkpoint_file_with_image_renders_on_the_gpu(gpu_ctx, tmp_path):
     rgb2, weight2 = scene2.global_render(p)
     scene2.close()
     assert np.array_equal(weight2, weight)
-    assert np.allclose(rgb2, rgb, rtol=1e-4, atol=1e-6)
+    assert np.allclose(rgb2, rgb, rtol=2e-4, atol=2e-5)

@@ -58,7 +58,7 @@ def test_full_size_sample_ranges_and_sampled_pixels(name, w, h, spp, ls, gpu_ctx
     assert weight.min() == spp and weight.max() == spp
     for x, y in zip(px[:8], py[:8]):
         want = oracle.resolve_pixel((img[int(y), int(x)] / spp).cpu().numpy())
-        assert np.allclose(rgb[int(y), int(x)], want, rtol=1e-4, atol=1e-5)
+        assert np.allclose(rgb[int(y), int(x)], want, rtol=2e-4, atol=2e-5)
     scene.close()
 
 

@@ -169,7 +169,7 @@ def test_random_world_render(n_circ, n_seg, w, h, gpu_ctx, oracle):
     orgb, ow, ospec, orays = oracle.render2d(world, p, threads=4, want_spectrum=True)
     assert st["rays"] == orays
     assert np.allclose(spec, ospec, rtol=1e-5, atol=1e-7)
-    assert np.allclose(rgb, orgb, rtol=1e-4, atol=1e-6)
+    assert np.allclose(rgb, orgb, rtol=2e-4, atol=2e-5)   # a channel near zero is a small difference of large XYZ terms
     scene.close()
 
 

@@ -95,7 +95,7 @@ def test_sample_ranges_add_up(gpu_ctx):
         assert float(whole.sum()) > 0
         rgb_a, wt = scene.resolve(whole.data_ptr(), w, h, n)
         rgb_b, _ = scene.resolve(parts.data_ptr(), w, h, n)
-        assert np.allclose(rgb_a, rgb_b, rtol=1e-4, atol=1e-5) and wt[0, 0] == n
+        assert np.allclose(rgb_a, rgb_b, rtol=2e-4, atol=2e-5) and wt[0, 0] == n
     finally:
         gpu_ctx.set_stream(None)
 
