@@ -29,6 +29,23 @@ def test_small_and_ragged_2d_renders(name, gpu_ctx, oracle):
     scene.close()
 
 
+@pytest.mark.parametrize("name", ["complex_world", "sample_world"])
+def test_parameters_at_their_limits(name, gpu_ctx, oracle):
+    """The most lambda-samples a call takes (65536), the deepest recursion (4095), many samples of few pixels, sample
+    indices that end at 2^31 - 1: the counters packed into the kernels' per-lane words have exactly this room."""
+    world = rt.World2D(name, seed=1)
+    scene = rt.Scene2D(gpu_ctx, world)
+    for (w, h, spp, ls, depth) in [(2, 2, 1, 65536, 3), (3, 1, 2, 4097, 4095), (5, 3, 16384, 1, 2), (2, 1, 7, 9999, 10)]:
+        p = params2d(w, h, spp, ls, depth, seed=3, sample_offset=2147483647 - spp, px_to_world=100.0)
+        gpu_ctx.reset_stats()
+        rgb, weight, spec = scene.global_render(p, want_spectrum=True)
+        st = gpu_ctx.stats()
+        orgb, ow, ospec, orays = oracle.render2d(world, p, threads=8, want_spectrum=True)
+        assert st["rays"] == orays, (w, h, spp, ls, depth)
+        assert np.allclose(spec, ospec, rtol=1e-4, atol=1e-6), (w, h, spp, ls, depth)   # up to 65536 terms per sum
+    scene.close()
+
+
 def test_8k_image_few_samples(gpu_ctx):
     import torch
     scene = rt.Scene2D(gpu_ctx, rt.World2D("complex_world", seed=1))
