@@ -74,7 +74,7 @@ struct SceneDev {
     // segments as the f32 filter reads them: one 40-byte record per PAIR of segments (the count padded to even)
     const SegPair *segp;
     SegBounds seg_bounds; // set per launch with the frame
-    const MatDev *mats;
+    const MatDev *mats; // per SLOT (the material of the slot's object): a hit's material does not wait for its primitive's record
     const float *spectra;
 };
 
@@ -378,6 +378,7 @@ RT_DEV Hit nearest_hit(SceneK S, double ox, double oy, double dx, double dy, boo
             int pid = 0;
             if (on) {
                 const SegX g = sex[s - n_circ];
+                asm volatile("" ::"v"(g.ax), "v"(g.ay), "v"(g.sx), "v"(g.sy)); // one wait for the whole record, see below
                 got = segment_t(ox, oy, dx, dy, g.ax, g.ay, g.sx, g.sy, t);
                 pid = g.pid;
             }
@@ -459,6 +460,9 @@ RT_DEV Hit nearest_hit(SceneK S, double ox, double oy, double dx, double dy, boo
                     } else {
                         const int k = s - n_circ;
                         const SegX g = sex[k];
+                        // both halves of the record are fetched before the test starts: left to itself the compiler
+                        // fetches a only behind the test of |d x s|, and a round then waits for memory twice
+                        asm volatile("" ::"v"(g.ax), "v"(g.ay), "v"(g.sx), "v"(g.sy));
                         got = segment_t(rox, roy, rdx, rdy, g.ax, g.ay, g.sx, g.sy, t);
                         pid = g.pid;
                     }
@@ -538,22 +542,19 @@ RT_DEV ShadeResult shade(SceneK S, Path &p, const Hit &h, float &value, double &
     const double hx = p.ox + h.t * p.dx, hy = p.oy + h.t * p.dy; // ray.origin + t * ray.dir
     double nx = 0.0, ny = 0.0, cx = 0.0, cy = 0.0;
     bool outside;
-    int obj;
+    const MatDev m = S->mats[h.slot];
     if (is_circle) {
         const CircleX c = S->cex[k];
         cx = c.cx;
         cy = c.cy;
         const double ex = cx - p.ox, ey = cy - p.oy; // is_inside(ray.origin), rt_common.rs:75-77
         outside = !((ex * ex + ey * ey) < c.r2);
-        obj = c.obj;
     } else {
         const SegX *g = S->sex + k;
         nx = g->nx;
         ny = g->ny;
         outside = (nx * p.dx + ny * p.dy) < 0.0; // rt_common.rs:262
-        obj = g->obj;
     }
-    const MatDev m = S->mats[obj];
     const float sv = S->spectra[m.spectrum * NBINS + p.li];
 
     // (1) classify

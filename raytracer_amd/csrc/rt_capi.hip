@@ -456,7 +456,7 @@ int32_t rt2d_scene_create(rt_ctx *ctx, const rt2d_scene_desc *d, rt2d_scene **ou
         rt2d::CircleX *cex = c.take<rt2d::CircleX>(ncp);
         rt2d::SegX *sex = c.take<rt2d::SegX>(ns);
         rt2d::SegPair *segp = c.take<rt2d::SegPair>((size_t)nsp2 / 2);
-        rt2d::MatDev *mats = c.take<rt2d::MatDev>(no);
+        rt2d::MatDev *mats = c.take<rt2d::MatDev>((size_t)ncp + ns); // per slot
         // at least one (zero) row: shade() may load a hit's spectrum value before it has classified the material, and
         // a scene of mirrors only has no spectra of its own
         float *spectra = c.take<float>((size_t)std::max(nsp, 1) * RT_NBINS);
@@ -509,6 +509,7 @@ int32_t rt2d_scene_create(rt_ctx *ctx, const rt2d_scene_desc *d, rt2d_scene **ou
                 rt2d::SegPair &q = H(segp)[ns >> 1];
                 q.ax[1] = q.ay[1] = q.bx[1] = q.by[1] = 0.0f;
             }
+            std::vector<rt2d::MatDev> by_object((size_t)std::max(no, 1));
             for (int i = 0; i < no; ++i) {
                 const rt2d_material &m = d->materials[i];
                 rt2d::MatDev md{};
@@ -523,8 +524,11 @@ int32_t rt2d_scene_create(rt_ctx *ctx, const rt2d_scene_desc *d, rt2d_scene **ou
                         if (d->spectra[(size_t)m.spectrum * RT_NBINS + b] != 0.0f) all_zero = false;
                     md.black = all_zero ? 1 : 0;
                 }
-                H(mats)[i] = md;
+                by_object[(size_t)i] = md;
             }
+            for (int k = 0; k < nc; ++k) H(mats)[k] = by_object[(size_t)d->circle_obj[corder[(size_t)k]]];
+            if (ncp > nc) H(mats)[nc] = rt2d::MatDev{}; // the padding circle is never hit
+            for (int k = 0; k < ns; ++k) H(mats)[ncp + k] = by_object[(size_t)d->seg_obj[sorder[(size_t)k]]];
             if (nsp) memcpy(H(spectra), d->spectra, sizeof(float) * (size_t)nsp * RT_NBINS);
         }
         S.n_circ = ncp; S.n_seg = ns; S.n_obj = no; S.pad_ = 0;
