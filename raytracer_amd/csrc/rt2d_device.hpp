@@ -342,7 +342,7 @@ RT_DEV Hit nearest_hit(SceneK S, double ox, double oy, double dx, double dy, boo
         int64_t bk = 0x7fffffffffffffffLL;
         uint64_t bps = ~0ull;
         auto keep = [&](bool got, double t, int pid, int s) {
-            const int64_t key = total_key(t);
+            const int64_t key = hit_key(t);
             const uint64_t ps = ((uint64_t)(uint32_t)pid << 32) | (uint64_t)(uint32_t)s;
             if (got && (key < bk || (key == bk && ps < bps))) {
                 bk = key;
@@ -390,7 +390,7 @@ RT_DEV Hit nearest_hit(SceneK S, double ox, double oy, double dx, double dy, boo
         RT_STAMP(prof, 2);
         Hit best;
         const bool found = bk != 0x7fffffffffffffffLL;
-        best.t = found ? __longlong_as_double(bk ^ (int64_t)((uint64_t)(bk >> 63) >> 1)) : 0.0;
+        best.t = found ? key_hit(bk) : 0.0;
         best.slot = found ? (int32_t)(uint32_t)bps : -1;
         best.pid = found ? (int32_t)(bps >> 32) : 0x7fffffff;
         return best;
@@ -467,7 +467,7 @@ RT_DEV Hit nearest_hit(SceneK S, double ox, double oy, double dx, double dy, boo
                         pid = g.pid;
                     }
                 }
-                const int64_t key = total_key(t);
+                const int64_t key = hit_key(t);
                 if (got) {
                     const int64_t old = __hip_atomic_fetch_min(&L.key[owner], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     if (key < old) L.pidslot[owner] = ~0ull;
@@ -498,7 +498,7 @@ RT_DEV Hit nearest_hit(SceneK S, double ox, double oy, double dx, double dy, boo
     const int64_t bk = L.key[lane];
     const uint64_t ps = L.pidslot[lane];
     const bool found = bk != 0x7fffffffffffffffLL;
-    best.t = found ? __longlong_as_double(bk ^ (int64_t)((uint64_t)(bk >> 63) >> 1)) : 0.0; // total_key is an involution
+    best.t = found ? key_hit(bk) : 0.0;
     best.slot = found ? (int32_t)(uint32_t)ps : -1;
     best.pid = found ? (int32_t)(ps >> 32) : 0x7fffffff;
     return best;

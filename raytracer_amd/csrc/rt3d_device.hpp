@@ -125,7 +125,7 @@ RT_DEV void consider(SceneK S, int slot, double ox, double oy, double oz, double
     double t;
     work.sphere_tests += 1;
     if (sphere_t(ox, oy, oz, dx, dy, dz, S->cx[slot], S->cy[slot], S->cz[slot], S->r2[slot], t)) {
-        const int64_t key = total_key(t);
+        const int64_t key = hit_key(t);
         const int sid = S->sid[slot];
         if (key < best_key || (key == best_key && sid < best.sid)) {
             best_key = key;

@@ -106,15 +106,15 @@ RT_DEV float expf_fixed(float x)
     return e * __uint_as_float((uint32_t)(n + 127) << 23);
 }
 
-// Key whose signed integer order is f64::total_cmp's order (the comparison
-// min_by / sort_by use at librt2d_reverse.rs:139, rt_common.rs:302,
-// 3d/src/rt.rs:224): -0.0 sorts before +0.0.
-RT_DEV int64_t total_key(double t)
-{
-    int64_t k = __double_as_longlong(t);
-    k ^= (int64_t)((uint64_t)(k >> 63) >> 1);
-    return k;
-}
+// The key the hit searches compare distances by: its signed integer order must be f64::total_cmp's (the comparison
+// min_by / sort_by use at librt2d_reverse.rs:139, rt_common.rs:302, 3d/src/rt.rs:224), for which -0.0 sorts before
+// +0.0.  Every distance a hit test accepts is positive, +0 or -0 (`t0 > 0.`, `t1 > 0.` for circles, rt_common.rs:90-98;
+// `t >= 0.`, which holds for -0.0, for segments and spheres, rt_common.rs:258, 3d/src/rt.rs:96-110) - never NaN, never
+// below zero - and on those the plain bit pattern, read as a signed integer, already has that order: -0.0 is the most
+// negative integer, +0.0 is zero, positive values ascend.  (The general key flips the low 63 bits of negative values;
+// five more instructions per test that would change nothing here.)
+RT_DEV int64_t hit_key(double t) { return (int64_t)__double_as_longlong(t); }
+RT_DEV double key_hit(int64_t k) { return __longlong_as_double(k); }
 
 RT_DEV int hi32(double x) { return __double2hiint(x); }
 
