@@ -344,10 +344,10 @@ RT_DEV Hit nearest_hit(SceneK S, double ox, double oy, double dx, double dy, boo
         auto keep = [&](bool got, double t, int pid, int s) {
             const int64_t key = hit_key(t);
             const uint64_t ps = ((uint64_t)(uint32_t)pid << 32) | (uint64_t)(uint32_t)s;
-            if (got && (key < bk || (key == bk && ps < bps))) {
-                bk = key;
-                bps = ps;
-            }
+            // selects, not a branch: around a branch the compiler copies both 64-bit values back and forth every round
+            const bool better = got & ((key < bk) | ((key == bk) & (ps < bps)));
+            bk = better ? key : bk;
+            bps = better ? ps : bps;
         };
         // circles first, then segments: a step of the wave then runs one kind of test, not both
         uint32_t mc = (n_circ >= 32) ? mw : (mw & ~(0xFFFFFFFFu >> n_circ));
