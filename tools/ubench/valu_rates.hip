@@ -100,6 +100,54 @@ template <int OP> __global__ void k(double *out, double sa, double sb)
 #define X(i) asm volatile("v_sqrt_f32 %0, %0" : "+v"(fa[i]));
             REP16(X)
 #undef X
+        } else if constexpr (OP == 19) {
+#define X(i) asm volatile("v_cvt_pk_i16_i32 %0, %0, %1" : "+v"(ia[i]) : "v"(ia[(i + 1) & 15]));
+            REP16(X)
+#undef X
+        } else if constexpr (OP == 20) {
+#define X(i) asm volatile("v_pk_lshrrev_b16 %0, 15, %0" : "+v"(ia[i]));
+            REP16(X)
+#undef X
+        } else if constexpr (OP == 21) {
+#define X(i) asm volatile("v_pk_mad_u16 %0, %0, %1, %2" : "+v"(ia[i]) : "v"(ia[(i + 1) & 15]), "v"(ia[(i + 2) & 15]));
+            REP16(X)
+#undef X
+        } else if constexpr (OP == 22) {
+#define X(i) asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(ia[i]) : "v"(ia[(i + 1) & 15]), "v"(ia[(i + 2) & 15]));
+            REP16(X)
+#undef X
+        } else if constexpr (OP == 23) {
+#define X(i) asm volatile("v_bfi_b32 %0, %0, %1, %2" : "+v"(ia[i]) : "v"(ia[(i + 1) & 15]), "v"(ia[(i + 2) & 15]));
+            REP16(X)
+#undef X
+        } else if constexpr (OP == 24) {
+#define X(i) asm volatile("v_lshl_or_b32 %0, %0, 1, %1" : "+v"(ia[i]) : "v"(ia[(i + 1) & 15]));
+            REP16(X)
+#undef X
+        } else if constexpr (OP == 25) {
+#define X(i) asm volatile("v_lshrrev_b32 %0, 31, %0" : "+v"(ia[i]));
+            REP16(X)
+#undef X
+        } else if constexpr (OP == 26) {
+#define X(i) asm volatile("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(ia[i]) : "v"(ia[(i + 1) & 15]), "v"(ia[(i + 2) & 15]));
+            REP16(X)
+#undef X
+        } else if constexpr (OP == 27) {
+#define X(i) asm volatile("v_cmp_lt_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(ia[i]) : "v"(fa[i]), "v"(fb) : "vcc");
+            REP16(X)
+#undef X
+        } else if constexpr (OP == 28) {
+#define X(i) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+            REP16(X)
+#undef X
+        } else if constexpr (OP == 29) {
+#define X(i) asm volatile("v_mov_b64 %0, %1" : "=v"(a[i]) : "v"(b));
+            REP16(X)
+#undef X
+        } else if constexpr (OP == 30) {
+#define X(i) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(ia[i]) : "v"(ia[(i + 1) & 15]) : "vcc");
+            REP16(X)
+#undef X
         }
     }
     double s = 0;
@@ -147,6 +195,18 @@ int main()
         run<16>("v_cmp_lt_f64", w, d_out);
         run<17>("v_cvt_f32_f64", w, d_out);
         run<18>("v_sqrt_f32", w, d_out);
+        run<19>("v_cvt_pk_i16_i32", w, d_out);
+        run<20>("v_pk_lshrrev_b16", w, d_out);
+        run<21>("v_pk_mad_u16", w, d_out);
+        run<22>("v_perm_b32", w, d_out);
+        run<23>("v_bfi_b32", w, d_out);
+        run<24>("v_lshl_or_b32", w, d_out);
+        run<25>("v_lshrrev_b32", w, d_out);
+        run<26>("v_bitop3_b32", w, d_out);
+        run<27>("v_cmp_lt_f32 + v_addc_co_u32", w, d_out);
+        run<28>("v_pk_mul_f32", w, d_out);
+        run<29>("v_mov_b64", w, d_out);
+        run<30>("v_cndmask_b32", w, d_out);
     }
     return 0;
 }
