@@ -711,12 +711,14 @@ RT_DEV void rand_hemisphere_wave(bool need, double nx, double ny, uint32_t c0, u
         const uint64_t seg = still ? ((okm >> seg_lo) & seg_mask) : 0ull;
         const int winner = seg ? seg_lo + (__ffsll((long long)seg) - 1) : lane;
         const double wvx = __shfl(vx, winner), wvy = __shfl(vy, winner), wl2 = __shfl(l2, winner);
-        if (seg) {
-            ovx = wvx; ovy = wvy; ol2 = wl2;
-            still = false;
-        } else if (still) {
-            base += (uint32_t)H;
-        }
+        // selects, not branches: around a branch the compiler keeps a second copy of the three doubles and moves them
+        // back every round
+        const bool won = seg != 0ull;
+        ovx = won ? wvx : ovx;
+        ovy = won ? wvy : ovy;
+        ol2 = won ? wl2 : ol2;
+        still = still & !won;
+        base += still ? (uint32_t)H : 0u;
         pending = __ballot(still);
     }
     if (need) {
